@@ -1,0 +1,451 @@
+"""TEST INFRASTRUCTURE (build container only): generate ``tests/golden/*.npz`` + ``isaaclab_amd/configs/*.json``
+by running the REAL reference managers / mdp terms / task cfgs (imported from /root/reference through
+``oracle/ref_import.py``) on the seeded synthetic state feed.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+
+What runs from the reference (unmodified, imported, not copied):
+  * task cfgs: CartpoleEnvCfg, AnymalCFlatEnvCfg, AnymalCRoughEnvCfg, G1RoughEnvCfg  -> ``cfg.to_dict()`` fixtures
+  * ActionManager/JointAction, TerminationManager, RewardManager, ObservationManager (+ uniform_noise)
+  * every mdp term the cfgs name, ``ArticulationData`` derived properties (root_lin_vel_b, projected_gravity_b ...),
+    ``ContactSensor.compute_first_contact``, ``grid_pattern``, ``quat_apply_yaw``, ``convert_height_field_to_mesh``,
+    and ``isaaclab.utils.math`` helpers on random + edge inputs.
+What cannot run (absent third-party): Warp ``mesh_query_ray`` -> ray hits come from the fp64
+brute-force oracle (``oracle/raycast_oracle.c``); rsl_rl -> no GAE/PPO goldens (parity unpinned).
+
+The step emulation follows ``ManagerBasedRLEnv.step`` (isaaclab/envs/manager_based_rl_env.py:153-242) and
+``_reset_idx`` (:347-392) with PhysX/scene/events/commands replaced by the feed.
+"""
+
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+
+ref_import.install()
+
+import isaaclab.utils.math as ref_math  # noqa: E402
+import isaaclab.utils.noise.noise_model as ref_noise_model  # noqa: E402
+import isaaclab.utils.string as ref_string  # noqa: E402
+from isaaclab.assets.articulation.articulation_data import ArticulationData  # noqa: E402
+from isaaclab.managers import ActionManager, ObservationManager, RewardManager, TerminationManager  # noqa: E402
+from isaaclab.sensors.contact_sensor import ContactSensor  # noqa: E402
+from isaaclab.sensors.ray_caster.patterns import patterns as ref_patterns  # noqa: E402
+from isaaclab.terrains.height_field.utils import convert_height_field_to_mesh  # noqa: E402
+
+from isaaclab_amd.robots import ANYMAL_C, CARTPOLE, G1, RobotSpec  # noqa: E402
+from isaaclab_amd.state_feed import DYNAMIC, STATIC, StateFeed  # noqa: E402
+from isaaclab_amd.terrain import make_rough_terrain  # noqa: E402
+from oracle.raycast import raycast_f64  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CONFIGS = os.path.join(ROOT, "isaaclab_amd", "configs")
+
+
+# --------------------------------------------------------------------------- cfg -> JSON
+def _jsonable(x):
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, slice):
+        return f"slice({x.start}, {x.stop}, {x.step})"
+    if isinstance(x, (str, int, bool)) or x is None:
+        return x
+    if isinstance(x, float):
+        if math.isinf(x) or math.isnan(x):
+            return str(x)
+        return x
+    if isinstance(x, (np.floating, np.integer)):
+        return x.item()
+    if isinstance(x, torch.Tensor):
+        return x.tolist()
+    return str(x)
+
+
+def dump_cfg(task: str, env_cfg, agent_cfg, robot: RobotSpec):
+    d = env_cfg.to_dict()
+    keep = {k: d[k] for k in ("decimation", "episode_length_s", "is_finite_horizon", "observations", "actions",
+                              "rewards", "terminations", "commands", "seed") if k in d}
+    keep["sim"] = {"dt": d["sim"]["dt"], "gravity": d["sim"].get("gravity", (0.0, 0.0, -9.81))}
+    scene = d["scene"]
+    keep["scene"] = {"num_envs": scene["num_envs"], "env_spacing": scene["env_spacing"]}
+    for name in ("height_scanner", "contact_forces"):
+        if scene.get(name) is not None:
+            s = dict(scene[name])
+            s.pop("visualizer_cfg", None)
+            keep["scene"][name] = s
+    if scene.get("terrain") is not None:
+        t = scene["terrain"]
+        tg = t.get("terrain_generator")
+        keep["scene"]["terrain"] = {
+            "terrain_type": t.get("terrain_type"),
+            "terrain_generator": None if tg is None else {k: tg[k] for k in ("size", "border_width", "num_rows",
+                                                                            "num_cols", "horizontal_scale",
+                                                                            "vertical_scale", "slope_threshold")},
+        }
+    out = {"task": task, "robot": robot.name, "env": keep, "agent": agent_cfg.to_dict()}
+    os.makedirs(CONFIGS, exist_ok=True)
+    with open(os.path.join(CONFIGS, task + ".json"), "w") as f:
+        json.dump(_jsonable(out), f, indent=1, sort_keys=False)
+    return out
+
+
+# --------------------------------------------------------------------------- fake scene
+class FakeArticulationData:
+    """Plain tensors for the PhysX-sourced buffers; DERIVED quantities run the reference's own property code."""
+
+    root_lin_vel_b = ArticulationData.root_lin_vel_b
+    root_ang_vel_b = ArticulationData.root_ang_vel_b
+    projected_gravity_b = ArticulationData.projected_gravity_b
+
+    def __init__(self, feed: StateFeed):
+        self._feed = feed
+        g = torch.tensor(feed.gravity_dir, dtype=torch.float32)
+        self.GRAVITY_VEC_W = ref_math.normalize(g.unsqueeze(0)).squeeze(0).repeat(feed.num_envs, 1)
+
+    def __getattr__(self, name):
+        if name == "root_link_quat_w":
+            name = "root_quat_w"
+        try:
+            return self._feed[name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+class FakeArticulation:
+    def __init__(self, robot: RobotSpec, feed: StateFeed):
+        self.robot = robot
+        self.data = FakeArticulationData(feed)
+        self.joint_names = list(robot.joint_names)
+        self.body_names = list(robot.body_names)
+        self.num_joints = robot.num_joints
+        self.num_bodies = robot.num_bodies
+        self.num_instances = feed.num_envs
+        self.device = "cpu"
+        self.targets = {}
+
+    def find_joints(self, name_keys, joint_subset=None, preserve_order=False):
+        return ref_string.resolve_matching_names(name_keys, self.joint_names, preserve_order)
+
+    def find_bodies(self, name_keys, preserve_order=False):
+        return ref_string.resolve_matching_names(name_keys, self.body_names, preserve_order)
+
+    def set_joint_position_target(self, target, joint_ids=None):
+        self.targets["pos"] = target
+
+    def set_joint_effort_target(self, target, joint_ids=None):
+        self.targets["effort"] = target
+
+
+class FakeContactSensor:
+    compute_first_contact = ContactSensor.compute_first_contact
+
+    def __init__(self, robot: RobotSpec, feed: StateFeed):
+        self.cfg = types.SimpleNamespace(track_air_time=True)
+        self.body_names = list(robot.body_names)
+        self.num_bodies = robot.num_bodies
+        self._feed = feed
+        outer = self
+
+        class _Data:
+            def __getattr__(self, name):
+                return outer._feed[name]
+
+        self.data = _Data()
+
+    def find_bodies(self, name_keys, preserve_order=False):
+        return ref_string.resolve_matching_names(name_keys, self.body_names, preserve_order)
+
+
+class FakeRayCaster:
+    def __init__(self):
+        self.data = types.SimpleNamespace(pos_w=None, quat_w=None, ray_hits_w=None)
+
+
+class FakeScene:
+    def __init__(self, entities: dict, sensors: dict, env_origins, cfg):
+        self._e = dict(entities)
+        self._e.update(sensors)
+        self.sensors = sensors
+        self.env_origins = env_origins
+        self.cfg = cfg
+        self.articulations = entities
+
+    def keys(self):
+        return list(self._e.keys())
+
+    def __getitem__(self, k):
+        return self._e[k]
+
+
+class FakeCommandManager:
+    def __init__(self, feed):
+        self._feed = feed
+
+    def get_command(self, name):
+        return self._feed["command"]
+
+
+def build_ref_env(env_cfg, robot: RobotSpec, feed: StateFeed):
+    N = feed.num_envs
+    robot_asset = FakeArticulation(robot, feed)
+    sensors = {}
+    if getattr(env_cfg.scene, "contact_forces", None) is not None:
+        sensors["contact_forces"] = FakeContactSensor(robot, feed)
+    if getattr(env_cfg.scene, "height_scanner", None) is not None:
+        sensors["height_scanner"] = FakeRayCaster()
+        pc = env_cfg.scene.height_scanner.pattern_cfg
+        R = len(pc.func(pc, "cpu")[1])
+        sensors["height_scanner"].data.pos_w = torch.zeros(N, 3)
+        sensors["height_scanner"].data.ray_hits_w = torch.zeros(N, R, 3)
+    env = types.SimpleNamespace()
+    env.num_envs = N
+    env.device = "cpu"
+    env.sim = types.SimpleNamespace(is_playing=lambda: True)
+    env.cfg = env_cfg
+    env.scene = FakeScene({"robot": robot_asset}, sensors, feed["env_origins"], env_cfg.scene)
+    env.step_dt = env_cfg.sim.dt * env_cfg.decimation
+    env.max_episode_length_s = env_cfg.episode_length_s
+    env.max_episode_length = math.ceil(env_cfg.episode_length_s / env.step_dt)
+    env.episode_length_buf = torch.zeros(N, dtype=torch.long)
+    env.command_manager = FakeCommandManager(feed)
+    env.action_manager = ActionManager(env_cfg.actions, env)
+    env.termination_manager = TerminationManager(env_cfg.terminations, env)
+    env.reward_manager = RewardManager(env_cfg.rewards, env)
+    env.observation_manager = ObservationManager(env_cfg.observations, env)
+    return env
+
+
+# --------------------------------------------------------------------------- ray caster (reference pieces + oracle hits)
+def ref_height_scanner(scanner_cfg, feed: StateFeed, mesh):
+    """ray_caster.py:201-260 with the Warp query replaced by the fp64 brute-force oracle."""
+    starts, dirs = scanner_cfg.pattern_cfg.func(scanner_cfg.pattern_cfg, "cpu")
+    R = len(dirs)
+    offset_pos = torch.tensor(list(scanner_cfg.offset.pos))
+    offset_quat = torch.tensor(list(scanner_cfg.offset.rot))
+    dirs = ref_math.quat_apply(offset_quat.repeat(R, 1), dirs)
+    starts = starts + offset_pos
+    N = feed.num_envs
+    starts = starts.repeat(N, 1, 1)
+    dirs = dirs.repeat(N, 1, 1)
+    pos_w = feed["root_pos_w"].clone()
+    quat_w = feed["root_quat_w"].clone()
+    assert scanner_cfg.attach_yaw_only
+    ray_starts_w = ref_math.quat_apply_yaw(quat_w.repeat(1, R), starts)
+    ray_starts_w += pos_w.unsqueeze(1)
+    verts, tris = mesh
+    hits, _, _ = raycast_f64(verts, tris, ray_starts_w.numpy().reshape(-1, 3), dirs.numpy().reshape(-1, 3),
+                             max_dist=scanner_cfg.max_distance)
+    return pos_w, quat_w, ray_starts_w, dirs, torch.from_numpy(hits).view(N, R, 3)
+
+
+# --------------------------------------------------------------------------- one task
+def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int, seed: int, mesh=None, extent=None):
+    torch.manual_seed(seed)
+    dump_cfg(task, env_cfg, agent_cfg, robot)
+    feed = StateFeed(robot, N, "cpu", seed=seed, num_snapshots=steps + 1, extent_xy=extent)
+    env = build_ref_env(env_cfg, robot, feed)
+    has_scan = "height_scanner" in env.scene.sensors
+    A = env.action_manager.total_action_dim
+    D = env.observation_manager.group_obs_dim["policy"][0]
+    gen = torch.Generator().manual_seed(seed + 1000)
+    rec: dict[str, np.ndarray] = {}
+
+    def put(name, t):
+        rec[name] = t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=A, obs_dim=D,
+                step_dt=env.step_dt, max_episode_length=env.max_episode_length,
+                max_episode_length_s=env.max_episode_length_s, gravity_dir=feed.gravity_dir,
+                reward_terms=env.reward_manager.active_terms, termination_terms=env.termination_manager.active_terms,
+                obs_terms=env.observation_manager.active_terms["policy"],
+                obs_term_dims=[list(d) for d in env.observation_manager.group_obs_term_dim["policy"]])
+    for n in STATIC:
+        put("static/" + n, feed[n])
+    if has_scan:
+        put("mesh/vertices", mesh[0])
+        put("mesh/triangles", mesh[1])
+
+    # uniform samples consumed by uniform_noise (observation_manager.py:313 -> noise_model.py:62): recorded so the
+    # HIP path can be fed the same draws (torch's CPU RNG stream cannot be reproduced in-kernel).
+    real_rand_like = torch.rand_like
+
+    def compute_obs(tag):
+        # the reference computes obs term by term; noisy terms call rand_like in term order.  Columns of `u` are
+        # laid out per OBS COLUMN (D wide): advance `col` to each term's offset.
+        u = torch.rand(N, D, generator=gen)
+        put(f"{tag}/noise_u", u)
+        # term-offset bookkeeping: patch so that draw k lands on the columns of the k-th noisy term
+        dims = [d[0] for d in env.observation_manager.group_obs_term_dim["policy"]]
+        cfgs = env.observation_manager._group_obs_term_cfgs["policy"]
+        offs = np.concatenate([[0], np.cumsum(dims)])
+        noisy_offsets = [int(offs[i]) for i, c in enumerate(cfgs) if c.noise]
+        it = iter(noisy_offsets)
+
+        def rand_like_at(x, *a, **k):
+            c0 = next(it)
+            return u[:, c0:c0 + x.shape[1]].clone()
+
+        ref_noise_model.torch.rand_like = rand_like_at  # same module object as torch; restore below
+        try:
+            obs = env.observation_manager.compute()["policy"]
+        finally:
+            torch.rand_like = real_rand_like
+        put(f"{tag}/obs", obs)
+        return obs
+
+    def update_scanner():
+        if not has_scan:
+            return
+        pos_w, quat_w, starts_w, dirs_w, hits = ref_height_scanner(env_cfg.scene.height_scanner, feed, mesh)
+        s = env.scene.sensors["height_scanner"]
+        s.data.pos_w, s.data.quat_w, s.data.ray_hits_w = pos_w, quat_w, hits
+        return starts_w, hits
+
+    # ---- reset() : ManagerBasedEnv.reset (manager_based_env.py:264-315) -> obs only
+    for n in DYNAMIC:
+        put(f"reset/in/{n}", feed[n])
+    sc = update_scanner()
+    if sc is not None:
+        put("reset/ray_starts_w", sc[0])
+        put("reset/ray_hits_w", sc[1])
+    compute_obs("reset")
+    # random episode lengths (RSL-RL init_at_random_ep_len) incl. some that time out on step 1..steps
+    ep = torch.randint(0, env.max_episode_length, (N,), generator=gen)
+    ep[::17] = env.max_episode_length - 1
+    ep[5::23] = env.max_episode_length - 2
+    env.episode_length_buf[:] = ep
+    put("reset/episode_length_buf", env.episode_length_buf)
+
+    for t in range(steps):
+        tag = f"step{t}"
+        action = (torch.randn(N, A, generator=gen)).clamp(-3, 3)
+        put(f"{tag}/action", action)
+        # -- pre-physics
+        env.action_manager.process_action(action)
+        term0 = next(iter(env.action_manager._terms.values()))
+        put(f"{tag}/processed_actions", term0.processed_actions)
+        put(f"{tag}/prev_action", env.action_manager.prev_action)
+        # -- physics: feed moves to the next snapshot
+        feed.advance()
+        for n in DYNAMIC:
+            put(f"{tag}/in/{n}", feed[n])
+        sc = update_scanner()  # RayCaster is lazy; pose does not change on reset in the feed
+        if sc is not None:
+            put(f"{tag}/ray_starts_w", sc[0])
+            put(f"{tag}/ray_hits_w", sc[1])
+        # -- post-physics (manager_based_rl_env.py:200-239)
+        env.episode_length_buf += 1
+        reset_buf = env.termination_manager.compute()
+        put(f"{tag}/reset_buf", reset_buf)
+        put(f"{tag}/terminated", env.termination_manager.terminated)
+        put(f"{tag}/time_outs", env.termination_manager.time_outs)
+        for name in env.termination_manager.active_terms:
+            put(f"{tag}/term_dones/{name}", env.termination_manager.get_term(name))
+        reward = env.reward_manager.compute(dt=env.step_dt)
+        put(f"{tag}/reward", reward)
+        put(f"{tag}/step_reward", env.reward_manager._step_reward)
+        for name in env.reward_manager.active_terms:
+            put(f"{tag}/episode_sums_pre_reset/{name}", env.reward_manager._episode_sums[name])
+        reset_env_ids = reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        put(f"{tag}/reset_env_ids", reset_env_ids)
+        log = {}
+        if len(reset_env_ids) > 0:
+            log.update(env.observation_manager.reset(reset_env_ids))
+            log.update(env.action_manager.reset(reset_env_ids))
+            log.update(env.reward_manager.reset(reset_env_ids))
+            log.update(env.termination_manager.reset(reset_env_ids))
+            env.episode_length_buf[reset_env_ids] = 0
+        rec[f"{tag}/log_json"] = np.array(json.dumps({k: float(v) for k, v in log.items()}))
+        for name in env.reward_manager.active_terms:
+            put(f"{tag}/episode_sums/{name}", env.reward_manager._episode_sums[name])
+        put(f"{tag}/episode_length_buf", env.episode_length_buf)
+        put(f"{tag}/action_after_reset", env.action_manager.action)
+        put(f"{tag}/prev_action_after_reset", env.action_manager.prev_action)
+        compute_obs(tag)
+
+    rec["meta_json"] = np.array(json.dumps(meta))
+    os.makedirs(GOLDEN, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN, task + ".npz"), **rec)
+    print(f"[golden] {task}: N={N} D={D} A={A} steps={steps} reward_terms={meta['reward_terms']}")
+
+
+# --------------------------------------------------------------------------- math / mesh / pattern fixtures
+def math_fixture():
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(1024, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    edge = torch.tensor([[1.0, 0, 0, 0], [0, 0, 0, 1.0], [0.70710678, 0, 0, 0.70710678], [0.5, 0.5, 0.5, 0.5],
+                         [0, 1.0, 0, 0], [0.70710678, 0.70710678, 0, 0]])
+    q = torch.cat([q, edge], 0)
+    v = torch.randn(q.shape[0], 3, generator=g) * 3.0
+    ang = torch.cat([torch.randn(1000, generator=g) * 10.0,
+                     torch.tensor([math.pi, -math.pi, 3 * math.pi, -3 * math.pi, 0.0, 2 * math.pi, 1e-8])])
+    out = dict(q=q, v=v, ang=ang,
+               quat_rotate_inverse=ref_math.quat_rotate_inverse(q, v), quat_rotate=ref_math.quat_rotate(q, v),
+               quat_apply=ref_math.quat_apply(q, v), yaw_quat=ref_math.yaw_quat(q),
+               quat_apply_yaw=ref_math.quat_apply_yaw(q, v), wrap_to_pi=ref_math.wrap_to_pi(ang),
+               convert_quat_to_wxyz=ref_math.convert_quat(q, to="wxyz"),
+               convert_quat_to_xyzw=ref_math.convert_quat(q, to="xyzw"), normalize=ref_math.normalize(v))
+    lo = torch.randn(q.shape[0], 3, generator=g) - 2
+    hi = lo + torch.rand(q.shape[0], 3, generator=g) * 4 + 0.1
+    out.update(lower=lo, upper=hi, scale_transform=ref_math.scale_transform(v, lo, hi))
+    np.savez_compressed(os.path.join(GOLDEN, "math.npz"), **{k: t.numpy() for k, t in out.items()})
+    print("[golden] math")
+
+
+def mesh_fixture():
+    rng = np.random.default_rng(3)
+    hf = np.rint(rng.uniform(0, 40, size=(21, 17)))
+    hf[5:9, 4:8] += 60  # a box with vertical walls so that slope snapping triggers
+    v0, t0 = convert_height_field_to_mesh(hf, 0.1, 0.005, None)
+    v1, t1 = convert_height_field_to_mesh(hf, 0.1, 0.005, 0.75)
+    cfg = types.SimpleNamespace(resolution=0.1, size=[1.6, 1.0], direction=(0.0, 0.0, -1.0), ordering="xy")
+    s, d = ref_patterns.grid_pattern(cfg, "cpu")
+    cfg2 = types.SimpleNamespace(resolution=0.25, size=[1.0, 0.5], direction=(0.0, 0.0, -1.0), ordering="yx")
+    s2, d2 = ref_patterns.grid_pattern(cfg2, "cpu")
+    np.savez_compressed(os.path.join(GOLDEN, "hf_mesh.npz"), hf=hf, v_none=v0, t_none=t0.astype(np.int64), v_thr=v1,
+                        t_thr=t1.astype(np.int64), grid_xy_starts=s.numpy(), grid_xy_dirs=d.numpy(),
+                        grid_yx_starts=s2.numpy(), grid_yx_dirs=d2.numpy())
+    print("[golden] hf_mesh + grid_pattern", s.shape, s2.shape)
+
+
+def main():
+    from isaaclab_tasks.manager_based.classic.cartpole.agents.rsl_rl_ppo_cfg import CartpolePPORunnerCfg
+    from isaaclab_tasks.manager_based.classic.cartpole.cartpole_env_cfg import CartpoleEnvCfg
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.agents.rsl_rl_ppo_cfg import (
+        AnymalCFlatPPORunnerCfg,
+        AnymalCRoughPPORunnerCfg,
+    )
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.flat_env_cfg import AnymalCFlatEnvCfg
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.rough_env_cfg import AnymalCRoughEnvCfg
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.g1.agents.rsl_rl_ppo_cfg import G1RoughPPORunnerCfg
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.g1.rough_env_cfg import G1RoughEnvCfg
+
+    math_fixture()
+    mesh_fixture()
+    verts, tris, ext = make_rough_terrain(2, 3, tile=4.0, border=3.0, seed=11)
+    mesh = (verts, tris)
+    run_task("Isaac-Cartpole-v0", CartpoleEnvCfg(), CartpolePPORunnerCfg(), CARTPOLE, N=64, steps=3, seed=101)
+    run_task("Isaac-Velocity-Flat-Anymal-C-v0", AnymalCFlatEnvCfg(), AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64,
+             steps=3, seed=102)
+    run_task("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64,
+             steps=3, seed=103, mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
+    run_task("Isaac-Velocity-Rough-G1-v0", G1RoughEnvCfg(), G1RoughPPORunnerCfg(), G1, N=64, steps=3, seed=104,
+             mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
+
+
+if __name__ == "__main__":
+    main()
