@@ -1,0 +1,256 @@
+/* imx.h -- C ABI of libimx: the MI355X (gfx950) implementation of IsaacLab's post-physics env-step hot path.
+ *
+ * The reference (godk1122/IsaacLab v2.1.0) has NO native ABI on this path: the boundary is two Python protocols
+ * (ManagerBasedRLEnv.step/reset and RslRlVecEnvWrapper).  This header is what the Python
+ * shim (isaaclab_amd/_lib.py, ctypes) binds; each entry point cites the reference code it replaces.
+ * Paths are relative to /root/reference/source/isaaclab/isaaclab unless noted.
+ *
+ * Conventions
+ *   - every pointer named *_d / inside imx_state_t / imx_buffers_t is a DEVICE pointer owned by the caller
+ *     (torch tensors); the library never allocates per call, never synchronises the stream, never frees them;
+ *   - all launches go to the hipStream_t passed in (the caller passes torch's current stream);
+ *   - return value: 0 = ok, non-zero = error; imx_last_error() gives the message (thread-local);
+ *   - floats are fp32, bools are 1-byte (torch.bool layout), indices int64 (torch.long), row-major contiguous.
+ */
+#ifndef IMX_H_
+#define IMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct imx_plan imx_plan_t; /* compiled term tables (one per env cfg) */
+typedef struct imx_mesh imx_mesh_t; /* terrain mesh + 2-D uniform grid acceleration structure */
+typedef void* imx_stream_t;         /* hipStream_t */
+
+/* ---- plan blob: int32 words written by isaaclab_amd/plan.py -------------------------------------------------- */
+#define IMX_MAGIC 0x31584D49 /* "IMX1" */
+#define IMX_PLAN_VERSION 2
+#define IMX_HEADER_WORDS 40
+#define IMX_REC_WORDS 20
+
+enum imx_header_word {
+    IMX_H_MAGIC = 0, IMX_H_VERSION, IMX_H_J, IMX_H_B, IMX_H_H, IMX_H_A, IMX_H_D, IMX_H_R, IMX_H_NTERM, IMX_H_NREW,
+    IMX_H_NOBS, IMX_H_NACT, IMX_H_MAX_EP_LEN, IMX_H_STEP_DT /*f32*/, IMX_H_TERM_OFF, IMX_H_REW_OFF, IMX_H_OBS_OFF,
+    IMX_H_ACT_OFF, IMX_H_TOTAL_WORDS, IMX_H_NB /* articulation bodies */, IMX_H_GRAV_X /*f32*/, IMX_H_GRAV_Y,
+    IMX_H_GRAV_Z, IMX_H_NREW_ALL /* reward terms incl. zero-weight */, IMX_H_RAY_OFF /* R*3 f32 local ray starts */,
+    IMX_H_RAYDIR_X /*f32*/, IMX_H_RAYDIR_Y, IMX_H_RAYDIR_Z, IMX_H_RAY_MAXDIST /*f32*/, IMX_H_MAX_EP_LEN_S /*f32*/,
+    IMX_H_NEXT_REW, IMX_H_NEXT_TERM, IMX_H_NEXT_OBS, IMX_H_RAY_YAW_ONLY, IMX_H_CMD_DIM
+};
+
+/* record layout (IMX_REC_WORDS int32/f32 words) */
+enum imx_rec_word {
+    IMX_R_OP = 0, IMX_R_IDS_OFF, IMX_R_NIDS, IMX_R_IDS2_OFF, IMX_R_NIDS2, IMX_R_WEIGHT /*f32; term: time_out flag*/,
+    IMX_R_P0 /*f32*/, IMX_R_P1, IMX_R_P2, IMX_R_P3, IMX_R_OUT /* obs: column offset; reward/term: term index */,
+    IMX_R_DIM, IMX_R_FLAGS, IMX_R_NOISE_LO /*f32*/, IMX_R_NOISE_HI, IMX_R_CLIP_LO, IMX_R_CLIP_HI, IMX_R_SCALE,
+    IMX_R_AUX0, IMX_R_AUX1
+};
+/* obs post-processing flags (observation_manager.py:310-318) */
+#define IMX_F_NOISE_ADD 1
+#define IMX_F_NOISE_SCALE 2
+#define IMX_F_NOISE_ABS 4
+#define IMX_F_CLIP 8
+#define IMX_F_SCALE 16
+#define IMX_F_QUAT_UNIQUE 32
+/* action record flags */
+#define IMX_F_ACT_DEFAULT_POS_OFFSET 1 /* JointPositionAction use_default_offset (joint_actions.py:152-154) */
+#define IMX_F_ACT_DEFAULT_VEL_OFFSET 2 /* JointVelocityAction (joint_actions.py:206-208) */
+#define IMX_F_ACT_CLIP 4
+
+/* termination ops -- envs/mdp/terminations.py */
+enum imx_term_op {
+    IMX_T_TIME_OUT = 1,            /* :30-32 */
+    IMX_T_ILLEGAL_CONTACT,         /* :150-158  ids=bodies p0=threshold */
+    IMX_T_JOINT_POS_MANUAL_LIMIT,  /* :90-105   ids=joints p0=lo p1=hi */
+    IMX_T_BAD_ORIENTATION,         /* :50-59    p0=limit_angle */
+    IMX_T_ROOT_HEIGHT_BELOW_MIN,   /* :62-72    p0=minimum_height */
+    IMX_T_JOINT_VEL_LIMIT,         /* :108-114  ids=joints */
+    IMX_T_JOINT_VEL_MANUAL_LIMIT,  /* :117-124  ids=joints p0=max_velocity */
+    IMX_T_JOINT_EFFORT_LIMIT,      /* :127-142  ids=joints (torch.isclose(computed, applied)) */
+    IMX_T_TERRAIN_OUT_OF_BOUNDS,   /* isaaclab_tasks .../velocity/mdp/terminations.py:24-52  p0=x_lim p1=y_lim */
+    IMX_T_EXTERNAL                 /* value computed by a Python term; aux0 = column in ext_term */
+};
+
+/* reward ops -- envs/mdp/rewards.py unless noted */
+enum imx_rew_op {
+    IMX_W_IS_ALIVE = 1,               /* :31-33 */
+    IMX_W_IS_TERMINATED,              /* :36-38 */
+    IMX_W_IS_TERMINATED_TERM,         /* :41-68   ids = termination term indices */
+    IMX_W_LIN_VEL_Z_L2,               /* :76-80 */
+    IMX_W_ANG_VEL_XY_L2,              /* :83-87 */
+    IMX_W_FLAT_ORIENTATION_L2,        /* :90-97 */
+    IMX_W_BASE_HEIGHT_L2,             /* :100-122 (no sensor) p0=target */
+    IMX_W_JOINT_TORQUES_L2,           /* :136-143 */
+    IMX_W_JOINT_VEL_L1,               /* :146-150 */
+    IMX_W_JOINT_VEL_L2,               /* :153-160 */
+    IMX_W_JOINT_ACC_L2,               /* :163-170 */
+    IMX_W_JOINT_DEVIATION_L1,         /* :173-179 */
+    IMX_W_JOINT_POS_LIMITS,           /* :182-196 */
+    IMX_W_JOINT_VEL_LIMITS,           /* :199-218 p0=soft_ratio */
+    IMX_W_APPLIED_TORQUE_LIMITS,      /* :226-242 */
+    IMX_W_ACTION_RATE_L2,             /* :245-247 */
+    IMX_W_ACTION_L2,                  /* :250-252 */
+    IMX_W_UNDESIRED_CONTACTS,         /* :260-268 ids=bodies p0=threshold */
+    IMX_W_CONTACT_FORCES,             /* :271-279 ids=bodies p0=threshold */
+    IMX_W_TRACK_LIN_VEL_XY_EXP,       /* :287-298 p0=std */
+    IMX_W_TRACK_ANG_VEL_Z_EXP,        /* :301-309 p0=std */
+    IMX_W_FEET_AIR_TIME,              /* isaaclab_tasks .../velocity/mdp/rewards.py:25-44 ids=bodies p0=threshold */
+    IMX_W_FEET_AIR_TIME_POSITIVE_BIPED, /* ...:47-66 */
+    IMX_W_FEET_SLIDE,                 /* ...:69-83  ids=sensor bodies ids2=asset bodies */
+    IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, /* ...:86-96 */
+    IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP,  /* ...:99-106 */
+    IMX_W_JOINT_POS_TARGET_L2,        /* isaaclab_tasks .../classic/cartpole/mdp/rewards.py:19-26 p0=target */
+    IMX_W_EXTERNAL                    /* aux0 = column in ext_reward */
+};
+
+/* observation ops -- envs/mdp/observations.py */
+enum imx_obs_op {
+    IMX_O_BASE_POS_Z = 1,   /* :33-37 */
+    IMX_O_BASE_LIN_VEL,     /* :40-44 */
+    IMX_O_BASE_ANG_VEL,     /* :47-51 */
+    IMX_O_PROJECTED_GRAVITY,/* :54-58 */
+    IMX_O_ROOT_POS_W,       /* :61-65 (minus env origins) */
+    IMX_O_ROOT_QUAT_W,      /* :68-83 */
+    IMX_O_ROOT_LIN_VEL_W,   /* :85-89 */
+    IMX_O_ROOT_ANG_VEL_W,   /* :92-96 */
+    IMX_O_JOINT_POS,        /* :104-111 */
+    IMX_O_JOINT_POS_REL,    /* :114-121 */
+    IMX_O_JOINT_POS_LIMIT_NORMALIZED, /* :124-137 */
+    IMX_O_JOINT_VEL,        /* :140-147 */
+    IMX_O_JOINT_VEL_REL,    /* :150-157 */
+    IMX_O_HEIGHT_SCAN,      /* :165-173 p0=offset */
+    IMX_O_LAST_ACTION,      /* :512-521 */
+    IMX_O_GENERATED_COMMANDS, /* :529-531 */
+    IMX_O_EXTERNAL          /* aux0 = column offset in ext_obs */
+};
+
+/* action ops -- envs/mdp/actions/joint_actions.py:130-139 (raw*scale+offset[,clamp]) */
+enum imx_act_op { IMX_A_JOINT_AFFINE = 1 };
+
+/* ---- per-step inputs: the tensors ArticulationData / ContactSensorData / CommandManager expose ---------------- */
+typedef struct imx_state {
+    const float* root_pos_w;            /* (N,3)   assets/articulation/articulation_data.py root_pos_w */
+    const float* root_quat_w;           /* (N,4) w,x,y,z */
+    const float* root_lin_vel_w;        /* (N,3) */
+    const float* root_ang_vel_w;        /* (N,3) */
+    const float* joint_pos;             /* (N,J) */
+    const float* joint_vel;             /* (N,J) */
+    const float* joint_acc;             /* (N,J) */
+    const float* applied_torque;        /* (N,J) */
+    const float* computed_torque;       /* (N,J) */
+    const float* default_joint_pos;     /* (N,J) */
+    const float* default_joint_vel;     /* (N,J) */
+    const float* soft_joint_pos_limits; /* (N,J,2) */
+    const float* soft_joint_vel_limits; /* (N,J) */
+    const float* body_lin_vel_w;        /* (N,NB,3) */
+    const float* command;               /* (N,CMD) command_manager.get_command() */
+    const float* net_forces_w_history;  /* (N,H,B,3) sensors/contact_sensor/contact_sensor_data.py */
+    const float* last_air_time;         /* (N,B) */
+    const float* current_air_time;      /* (N,B) */
+    const float* current_contact_time;  /* (N,B) */
+    const float* env_origins;           /* (N,3) scene.env_origins */
+    const float* ext_reward;            /* (N,next_rew) values of Python-evaluated reward terms, or NULL */
+    const uint8_t* ext_term;            /* (N,next_term) */
+    const float* ext_obs;               /* (N,next_obs) */
+} imx_state_t;
+
+/* ---- manager state + outputs (caller-owned, persistent across steps) ------------------------------------------ */
+typedef struct imx_buffers {
+    int64_t* episode_length_buf; /* (N)   envs/manager_based_rl_env.py:200 */
+    float* action;               /* (N,A) managers/action_manager.py:318-331 */
+    float* prev_action;          /* (N,A) */
+    float* processed_action;     /* (N,A) */
+    float* reward_buf;           /* (N)   managers/reward_manager.py:128-157 */
+    float* episode_sums;         /* (NREW_ALL,N) */
+    float* step_reward;          /* (N,NREW_ALL) */
+    uint8_t* term_dones;         /* (NTERM,N) managers/termination_manager.py:151-174 */
+    uint8_t* terminated;         /* (N) */
+    uint8_t* truncated;          /* (N) */
+    uint8_t* reset_buf;          /* (N) */
+    int64_t* reset_env_ids;      /* (N) ascending ids of reset envs; valid prefix = counters[0] */
+    int32_t* counters;           /* (8) [0] reset count [1] ticket [2] step counter (RNG) [3..] reserved */
+    float* log_out;              /* (NREW_ALL + NTERM + 1) Episode_Reward/<term>, Episode_Termination/<term>, count */
+    float* obs;                  /* (N,D) managers/observation_manager.py:238-335 */
+    void* scratch;               /* imx_plan_scratch_bytes(plan, N) bytes */
+} imx_buffers_t;
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+const char* imx_version(void);
+const char* imx_last_error(void);
+int imx_device_count(void);
+
+/* term compiler output -> device tables.  Replaces ManagerBase._prepare_terms (managers/manager_base.py:160). */
+int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** out);
+void imx_plan_destroy(imx_plan_t* plan);
+size_t imx_plan_scratch_bytes(const imx_plan_t* plan, int64_t num_envs);
+int imx_plan_obs_dim(const imx_plan_t* plan);
+
+/* ActionManager.process_action (managers/action_manager.py:318-337) + JointAction.process_actions
+ * (envs/mdp/actions/joint_actions.py:130-139); pre_clip = RslRlVecEnvWrapper clip_actions
+ * (isaaclab_rl/rsl_rl/vecenv_wrapper.py:173-174) or +inf. */
+int imx_action_process(const imx_plan_t* plan, int64_t num_envs, const float* actions_d, float pre_clip,
+                       const imx_state_t* state, const imx_buffers_t* buf, imx_stream_t stream);
+
+/* Post-physics, pre-reset half of ManagerBasedRLEnv.step (envs/manager_based_rl_env.py:200-230):
+ * episode_length_buf += 1; TerminationManager.compute; RewardManager.compute(dt); reset_env_ids = nonzero(reset_buf);
+ * the manager-side part of _reset_idx (:347-392): Episode_* log reductions, episode sums / actions / episode length
+ * zeroed for reset envs. */
+int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state,
+                             const imx_buffers_t* buf, imx_stream_t stream);
+
+/* ObservationManager.compute (managers/observation_manager.py:238-335) fused with RayCaster._update_buffers_impl
+ * (sensors/ray_caster/ray_caster.py:220-260) + raycast_mesh (utils/warp/ops.py:24-127).
+ * noise_u_d: optional (N,D) uniform [0,1) samples replacing torch.rand_like (parity mode); NULL -> in-kernel
+ * counter-based RNG keyed by (seed, step counter, env, column).  ray_hits_out_d: optional (N,R,3). */
+int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
+                     const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
+                     float* ray_hits_out_d, imx_stream_t stream);
+
+/* ArticulationData.root_lin_vel_b / root_ang_vel_b / projected_gravity_b
+ * (assets/articulation/articulation_data.py:512-515,603-619) = quat_rotate_inverse (utils/math.py:605-625). */
+int imx_root_frame(int64_t num_envs, const float* quat_wxyz_d, const float* lin_vel_w_d, const float* ang_vel_w_d,
+                   float gx, float gy, float gz, float* lin_vel_b_d, float* ang_vel_b_d, float* proj_gravity_d,
+                   imx_stream_t stream);
+
+/* convert_to_warp_mesh (utils/warp/ops.py:130-145): host vertices/triangles -> device mesh + grid. cell<=0: auto */
+int imx_mesh_create(const float* vertices_h, int64_t num_vertices, const uint32_t* triangles_h, int64_t num_triangles,
+                    float cell_size, imx_mesh_t** out);
+void imx_mesh_destroy(imx_mesh_t* mesh);
+/* info[0..7] = nx, ny, num_triangles, num_cell_refs, max refs per cell, x0, y0, cell (floats bit-cast for 5..7) */
+int imx_mesh_info(const imx_mesh_t* mesh, int64_t* info8);
+
+/* raycast_mesh (utils/warp/ops.py:24-127): closest hit per ray, misses = +inf / face -1. */
+int imx_raycast(const imx_mesh_t* mesh, const float* ray_starts_d, const float* ray_dirs_d, int64_t num_rays,
+                float max_dist, float* ray_hits_d, float* ray_distance_d, int32_t* ray_face_id_d,
+                imx_stream_t stream);
+
+/* rsl_rl (3rd-party, v2.3.1) RolloutStorage.compute_returns: GAE backward scan over (T,N) + advantage
+ * normalisation over all T*N.  scratch_d: >= imx_gae_scratch_bytes(T,N).  PARITY UNPINNED (rsl_rl absent). */
+size_t imx_gae_scratch_bytes(int64_t T, int64_t N);
+int imx_gae(int64_t T, int64_t N, const float* rewards_d, const float* values_d, const uint8_t* dones_d,
+            const float* last_values_d, float gamma, float lam, int normalize, float* returns_d,
+            float* advantages_d, void* scratch_d, imx_stream_t stream);
+
+/* rsl_rl PPO.update elementwise part: surrogate / clipped value / entropy losses and the KL estimate for a
+ * minibatch of M samples with A action dims.  fwd writes out4 = {surrogate_loss, value_loss, entropy_mean, kl_mean};
+ * bwd writes d(loss)/d(mu), d(loss)/d(sigma), d(loss)/d(value) for
+ * loss = surrogate + value_loss_coef*value_loss - entropy_coef*entropy.  PARITY UNPINNED (rsl_rl absent). */
+size_t imx_ppo_scratch_bytes(int64_t M);
+int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, const float* actions_d,
+                     const float* old_logp_d, const float* old_mu_d, const float* old_sigma_d,
+                     const float* advantages_d, const float* returns_d, const float* values_d,
+                     const float* old_values_d, float clip_param, int use_clipped_value_loss, float* out4_d,
+                     void* scratch_d, imx_stream_t stream);
+int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, const float* actions_d,
+                     const float* old_logp_d, const float* advantages_d, const float* returns_d,
+                     const float* values_d, const float* old_values_d, float clip_param,
+                     int use_clipped_value_loss, float value_loss_coef, float entropy_coef, float grad_scale,
+                     float* dmu_d, float* dsigma_d, float* dvalue_d, imx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMX_H_ */

@@ -1,0 +1,110 @@
+"""ctypes binding of libimx.so (``include/imx.h``).  There is NO fallback: if the library cannot be loaded the
+product path raises -- a silent eager/CPU path would void every parity and performance claim."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimx.so")
+
+# field order must match include/imx.h
+STATE_FIELDS = (
+    "root_pos_w", "root_quat_w", "root_lin_vel_w", "root_ang_vel_w", "joint_pos", "joint_vel", "joint_acc",
+    "applied_torque", "computed_torque", "default_joint_pos", "default_joint_vel", "soft_joint_pos_limits",
+    "soft_joint_vel_limits", "body_lin_vel_w", "command", "net_forces_w_history", "last_air_time",
+    "current_air_time", "current_contact_time", "env_origins", "ext_reward", "ext_term", "ext_obs",
+)
+BUFFER_FIELDS = (
+    "episode_length_buf", "action", "prev_action", "processed_action", "reward_buf", "episode_sums", "step_reward",
+    "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch",
+)
+
+
+class ImxState(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in STATE_FIELDS]
+
+
+class ImxBuffers(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in BUFFER_FIELDS]
+
+
+class ImxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "imx_version": (c_char_p, []),
+    "imx_last_error": (c_char_p, []),
+    "imx_device_count": (c_int, []),
+    "imx_plan_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "imx_plan_destroy": (None, [c_void_p]),
+    "imx_plan_scratch_bytes": (c_size_t, [c_void_p, c_int64]),
+    "imx_plan_obs_dim": (c_int, [c_void_p]),
+    "imx_action_process": (c_int, [c_void_p, c_int64, c_void_p, c_float, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
+    "imx_terminations_rewards": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
+    "imx_observations": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p, c_void_p, c_uint64,
+                                 c_int, c_void_p, c_void_p]),
+    "imx_root_frame": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "imx_mesh_create": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, POINTER(c_void_p)]),
+    "imx_mesh_destroy": (None, [c_void_p]),
+    "imx_mesh_info": (c_int, [c_void_p, POINTER(c_int64)]),
+    "imx_raycast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imx_gae_scratch_bytes": (c_size_t, [c_int64, c_int64]),
+    "imx_gae": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
+                        c_void_p, c_void_p, c_void_p]),
+    "imx_ppo_scratch_bytes": (c_size_t, [c_int64]),
+    "imx_ppo_loss_fwd": (c_int, [c_int64, c_int64] + [c_void_p] * 10 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "imx_ppo_loss_bwd": (c_int, [c_int64, c_int64] + [c_void_p] * 8 + [c_float, c_int, c_float, c_float, c_float, c_void_p,
+                                                                      c_void_p, c_void_p, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libimx.so (building it when hipcc is available and the library is stale or missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+
+        _build.build()
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # fail loudly: never substitute another implementation
+        raise ImxError(f"cannot load {LIB_PATH}: {e}. Run `python -m isaaclab_amd.build` (hipcc, gfx950).") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != 0:
+        raise ImxError(lib().imx_last_error().decode())
+
+
+def ptr(t) -> int | None:
+    """Device/host pointer of a contiguous torch tensor (None stays NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ImxError("libimx needs contiguous tensors")
+    return t.data_ptr()
+
+
+def current_stream(device) -> int:
+    import torch
+
+    if device.type != "cuda":
+        raise ImxError("libimx kernels only run on a GPU (device=%s)" % device)
+    return torch.cuda.current_stream(device).cuda_stream

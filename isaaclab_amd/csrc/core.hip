@@ -1,0 +1,208 @@
+// libimx core: error plumbing, version, plan parsing/validation/upload.
+//
+// The plan is the compiled form of the reference's manager term lists
+// (ManagerBase._prepare_terms, reference isaaclab/managers/manager_base.py:160 and the per-manager overrides):
+// plan.py resolves names/regexes on the host and emits int32 words; here they are validated once so that the
+// kernels can index without bounds checks.
+#include <cstring>
+#include <memory>
+
+#include "imx_internal.h"
+
+static thread_local std::string g_err;
+
+void imx_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* imx_version(void) { return "libimx 0.1 (gfx950; plan v2)"; }
+extern "C" const char* imx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int imx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline float wf(int32_t w) {
+    float f;
+    memcpy(&f, &w, 4);
+    return f;
+}
+
+static int check_ids(const std::vector<int32_t>& w, int off, int n, int limit, const char* what, int rec) {
+    if (n == 0) return 0;
+    IMX_REQUIRE(off >= IMX_HEADER_WORDS && n > 0 && (size_t)off + (size_t)n <= w.size(),
+                "plan: %s list of record %d out of range (off=%d n=%d)", what, rec, off, n);
+    for (int i = 0; i < n; ++i)
+        IMX_REQUIRE(w[off + i] >= 0 && w[off + i] < limit, "plan: %s index %d of record %d outside [0,%d)", what,
+                    w[off + i], rec, limit);
+    return 0;
+}
+
+extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** out) {
+    IMX_REQUIRE(blob && out, "imx_plan_create: null argument");
+    IMX_REQUIRE(nwords >= IMX_HEADER_WORDS, "plan: blob too small (%zu words)", nwords);
+    IMX_REQUIRE(blob[IMX_H_MAGIC] == IMX_MAGIC, "plan: bad magic 0x%x", blob[IMX_H_MAGIC]);
+    IMX_REQUIRE(blob[IMX_H_VERSION] == IMX_PLAN_VERSION, "plan: version %d, library expects %d", blob[IMX_H_VERSION],
+                IMX_PLAN_VERSION);
+    IMX_REQUIRE((size_t)blob[IMX_H_TOTAL_WORDS] == nwords, "plan: total_words %d != %zu", blob[IMX_H_TOTAL_WORDS],
+                nwords);
+    auto p = new imx_plan();
+    std::unique_ptr<imx_plan> guard(p);
+    p->host.assign(blob, blob + nwords);
+    auto& w = p->host;
+    p->J = w[IMX_H_J]; p->B = w[IMX_H_B]; p->H = w[IMX_H_H]; p->A = w[IMX_H_A]; p->D = w[IMX_H_D];
+    p->R = w[IMX_H_R]; p->NB = w[IMX_H_NB]; p->CMD = w[IMX_H_CMD_DIM];
+    p->nterm = w[IMX_H_NTERM]; p->nrew = w[IMX_H_NREW]; p->nobs = w[IMX_H_NOBS]; p->nact = w[IMX_H_NACT];
+    p->nrew_all = w[IMX_H_NREW_ALL];
+    p->term_off = w[IMX_H_TERM_OFF]; p->rew_off = w[IMX_H_REW_OFF]; p->obs_off = w[IMX_H_OBS_OFF];
+    p->act_off = w[IMX_H_ACT_OFF]; p->ray_off = w[IMX_H_RAY_OFF];
+    IMX_REQUIRE(p->J >= 0 && p->J <= 4096 && p->B >= 0 && p->B <= 4096 && p->H >= 0 && p->H <= 64, "plan: bad J/B/H");
+    IMX_REQUIRE(p->A >= 0 && p->A <= 4096 && p->D >= 0 && p->D <= 65535 && p->R >= 0 && p->R <= 65535, "plan: bad A/D/R");
+    IMX_REQUIRE(p->nterm >= 0 && p->nterm <= 32, "plan: at most 32 termination terms are supported (got %d)", p->nterm);
+    IMX_REQUIRE(p->nrew >= 0 && p->nrew <= p->nrew_all && p->nrew_all <= 256, "plan: bad reward term counts");
+    IMX_REQUIRE(p->nobs >= 0 && p->nobs <= 4096 && p->nact >= 0 && p->nact <= 64, "plan: bad obs/action term counts");
+    IMX_REQUIRE(p->CMD >= 0 && p->CMD <= 16, "plan: bad command dim");
+    auto table_ok = [&](int off, int n) {
+        return n == 0 || (off >= IMX_HEADER_WORDS && (size_t)off + (size_t)n * IMX_REC_WORDS <= nwords);
+    };
+    IMX_REQUIRE(table_ok(p->term_off, p->nterm) && table_ok(p->rew_off, p->nrew) && table_ok(p->obs_off, p->nobs) &&
+                    table_ok(p->act_off, p->nact),
+                "plan: record table out of range");
+    if (p->R > 0)
+        IMX_REQUIRE(p->ray_off >= IMX_HEADER_WORDS && (size_t)p->ray_off + (size_t)p->R * 3 <= nwords,
+                    "plan: ray table out of range");
+
+    // ---- terminations
+    for (int k = 0; k < p->nterm; ++k) {
+        const int32_t* r = &w[p->term_off + k * IMX_REC_WORDS];
+        const int op = r[IMX_R_OP];
+        IMX_REQUIRE(op >= IMX_T_TIME_OUT && op <= IMX_T_EXTERNAL, "plan: unknown termination op %d", op);
+        IMX_REQUIRE(r[IMX_R_OUT] == k, "plan: termination record %d has index %d", k, r[IMX_R_OUT]);
+        const bool body = op == IMX_T_ILLEGAL_CONTACT;
+        if (check_ids(w, r[IMX_R_IDS_OFF], r[IMX_R_NIDS], body ? p->B : p->J, body ? "body" : "joint", k)) return 1;
+        if (op == IMX_T_EXTERNAL)
+            IMX_REQUIRE(r[IMX_R_AUX0] >= 0 && r[IMX_R_AUX0] < w[IMX_H_NEXT_TERM], "plan: ext_term column out of range");
+    }
+    // ---- rewards
+    for (int k = 0; k < p->nrew; ++k) {
+        const int32_t* r = &w[p->rew_off + k * IMX_REC_WORDS];
+        const int op = r[IMX_R_OP];
+        IMX_REQUIRE(op >= IMX_W_IS_ALIVE && op <= IMX_W_EXTERNAL, "plan: unknown reward op %d", op);
+        IMX_REQUIRE(r[IMX_R_OUT] >= 0 && r[IMX_R_OUT] < p->nrew_all, "plan: reward index out of range");
+        int limit = p->J;
+        const char* what = "joint";
+        if (op == IMX_W_UNDESIRED_CONTACTS || op == IMX_W_CONTACT_FORCES || op == IMX_W_FEET_AIR_TIME ||
+            op == IMX_W_FEET_AIR_TIME_POSITIVE_BIPED || op == IMX_W_FEET_SLIDE) {
+            limit = p->B;
+            what = "body";
+        } else if (op == IMX_W_IS_TERMINATED_TERM) {
+            limit = p->nterm;
+            what = "termination-term";
+        }
+        if (check_ids(w, r[IMX_R_IDS_OFF], r[IMX_R_NIDS], limit, what, k)) return 1;
+        if (op == IMX_W_FEET_SLIDE) {
+            IMX_REQUIRE(r[IMX_R_NIDS2] == r[IMX_R_NIDS], "plan: feet_slide needs equally many sensor and asset bodies");
+            if (check_ids(w, r[IMX_R_IDS2_OFF], r[IMX_R_NIDS2], p->NB, "asset body", k)) return 1;
+        }
+        if (op == IMX_W_EXTERNAL)
+            IMX_REQUIRE(r[IMX_R_AUX0] >= 0 && r[IMX_R_AUX0] < w[IMX_H_NEXT_REW], "plan: ext_reward column out of range");
+    }
+    // ---- observations: every column covered exactly once
+    std::vector<int32_t> col(p->D, -1);
+    for (int k = 0; k < p->nobs; ++k) {
+        const int32_t* r = &w[p->obs_off + k * IMX_REC_WORDS];
+        const int op = r[IMX_R_OP];
+        IMX_REQUIRE(op >= IMX_O_BASE_POS_Z && op <= IMX_O_EXTERNAL, "plan: unknown observation op %d", op);
+        const int o = r[IMX_R_OUT], d = r[IMX_R_DIM];
+        IMX_REQUIRE(o >= 0 && d > 0 && o + d <= p->D, "plan: observation record %d columns [%d,%d) outside D=%d", k, o,
+                    o + d, p->D);
+        const bool joint = op == IMX_O_JOINT_POS || op == IMX_O_JOINT_POS_REL || op == IMX_O_JOINT_VEL ||
+                           op == IMX_O_JOINT_VEL_REL || op == IMX_O_JOINT_POS_LIMIT_NORMALIZED;
+        if (joint) {
+            IMX_REQUIRE(r[IMX_R_NIDS] == d, "plan: joint observation dim %d != number of joint ids %d", d, r[IMX_R_NIDS]);
+            if (check_ids(w, r[IMX_R_IDS_OFF], r[IMX_R_NIDS], p->J, "joint", k)) return 1;
+        }
+        if (op == IMX_O_HEIGHT_SCAN) {
+            IMX_REQUIRE(d == p->R && p->R > 0, "plan: height_scan dim %d != number of rays %d", d, p->R);
+            p->needs_mesh = true;
+        }
+        if (op == IMX_O_LAST_ACTION) IMX_REQUIRE(d == p->A, "plan: last_action dim %d != A=%d", d, p->A);
+        if (op == IMX_O_GENERATED_COMMANDS) IMX_REQUIRE(d == p->CMD, "plan: command dim mismatch");
+        if (op == IMX_O_EXTERNAL)
+            IMX_REQUIRE(r[IMX_R_AUX0] >= 0 && r[IMX_R_AUX0] + d <= w[IMX_H_NEXT_OBS], "plan: ext_obs columns out of range");
+        static const int fixed_dim[] = {0, 1, 3, 3, 3, 3, 4, 3, 3};
+        if (op <= IMX_O_ROOT_ANG_VEL_W) IMX_REQUIRE(d == fixed_dim[op], "plan: observation op %d must have dim %d", op, fixed_dim[op]);
+        for (int j = 0; j < d; ++j) {
+            IMX_REQUIRE(col[o + j] < 0, "plan: observation column %d written twice", o + j);
+            col[o + j] = (k << 16) | j;
+        }
+    }
+    for (int c = 0; c < p->D; ++c) IMX_REQUIRE(col[c] >= 0, "plan: observation column %d not covered", c);
+    // ---- actions
+    int acols = 0;
+    for (int k = 0; k < p->nact; ++k) {
+        const int32_t* r = &w[p->act_off + k * IMX_REC_WORDS];
+        IMX_REQUIRE(r[IMX_R_OP] == IMX_A_JOINT_AFFINE, "plan: unknown action op %d", r[IMX_R_OP]);
+        IMX_REQUIRE(r[IMX_R_OUT] == acols && r[IMX_R_DIM] == r[IMX_R_NIDS], "plan: action record %d layout", k);
+        if (check_ids(w, r[IMX_R_IDS_OFF], r[IMX_R_NIDS], p->J, "joint", k)) return 1;
+        // optional per-joint scale / offset / clip tables (dim floats each) referenced by aux words
+        acols += r[IMX_R_DIM];
+    }
+    IMX_REQUIRE(acols == p->A || p->nact == 0, "plan: action terms cover %d columns, A=%d", acols, p->A);
+
+    // ---- append column tables: [col (D)] [order (D)] with ray columns first
+    p->col_off = (int)w.size();
+    w.insert(w.end(), col.begin(), col.end());
+    p->order_off = (int)w.size();
+    std::vector<int32_t> order;
+    order.reserve(p->D);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c = 0; c < p->D; ++c) {
+            const int k = col[c] >> 16;
+            const bool ray = w[p->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN;
+            if (ray == (pass == 0)) order.push_back(c);
+        }
+    for (int c = 0; c < p->D; ++c)
+        if (w[p->obs_off + (col[c] >> 16) * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) p->n_ray_cols++;
+    w.insert(w.end(), order.begin(), order.end());
+
+    if (imx_device_count() > 0) {
+        IMX_HIP(hipMalloc((void**)&p->dev, w.size() * sizeof(int32_t)));
+        IMX_HIP(hipMemcpy(p->dev, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    *out = guard.release();
+    return 0;
+}
+
+extern "C" void imx_plan_destroy(imx_plan_t* plan) {
+    if (!plan) return;
+    if (plan->dev) (void)hipFree(plan->dev);
+    delete plan;
+}
+
+extern "C" int imx_plan_obs_dim(const imx_plan_t* plan) { return plan ? plan->D : -1; }
+
+PlanView imx_plan_view(const imx_plan* p) {
+    PlanView v;
+    const auto& w = p->host;
+    v.w = p->dev;
+    v.J = p->J; v.B = p->B; v.H = p->H; v.A = p->A; v.D = p->D; v.R = p->R; v.NB = p->NB; v.CMD = p->CMD;
+    v.nterm = p->nterm; v.nrew = p->nrew; v.nobs = p->nobs; v.nact = p->nact; v.nrew_all = p->nrew_all;
+    v.term_off = p->term_off; v.rew_off = p->rew_off; v.obs_off = p->obs_off; v.act_off = p->act_off;
+    v.ray_off = p->ray_off; v.col_off = p->col_off; v.order_off = p->order_off; v.n_ray_cols = p->n_ray_cols;
+    v.max_ep_len = w[IMX_H_MAX_EP_LEN];
+    v.step_dt = wf(w[IMX_H_STEP_DT]);
+    v.max_ep_len_s = wf(w[IMX_H_MAX_EP_LEN_S]);
+    v.gx = wf(w[IMX_H_GRAV_X]); v.gy = wf(w[IMX_H_GRAV_Y]); v.gz = wf(w[IMX_H_GRAV_Z]);
+    v.rdx = wf(w[IMX_H_RAYDIR_X]); v.rdy = wf(w[IMX_H_RAYDIR_Y]); v.rdz = wf(w[IMX_H_RAYDIR_Z]);
+    v.ray_max_dist = wf(w[IMX_H_RAY_MAXDIST]);
+    v.ray_yaw_only = w[IMX_H_RAY_YAW_ONLY];
+    return v;
+}

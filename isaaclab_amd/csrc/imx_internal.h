@@ -1,0 +1,146 @@
+// Internal declarations shared by the libimx translation units (gfx950 only; no portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/imx.h"
+
+#define IMX_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------------------------------------------
+void imx_set_error(const char* fmt, ...);
+#define IMX_FAIL(...)               \
+    do {                            \
+        imx_set_error(__VA_ARGS__); \
+        return 1;                   \
+    } while (0)
+#define IMX_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) IMX_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define IMX_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) IMX_FAIL(__VA_ARGS__); \
+    } while (0)
+
+// ---- plan ---------------------------------------------------------------------------------------------------------
+struct imx_plan {
+    std::vector<int32_t> host;  // validated blob + appended column tables
+    int32_t* dev = nullptr;     // device copy (null when no GPU is visible)
+    int J = 0, B = 0, H = 0, A = 0, D = 0, R = 0, NB = 0, CMD = 3;
+    int nterm = 0, nrew = 0, nobs = 0, nact = 0, nrew_all = 0;
+    int term_off = 0, rew_off = 0, obs_off = 0, act_off = 0, ray_off = 0;
+    int col_off = 0;    // D words: (obs record index << 16) | local index j
+    int order_off = 0;  // D words: column permutation, ray columns first
+    int n_ray_cols = 0;
+    bool needs_mesh = false;
+};
+
+// view passed by value to kernels
+struct PlanView {
+    const int32_t* w;  // device blob
+    int J, B, H, A, D, R, NB, CMD;
+    int nterm, nrew, nobs, nact, nrew_all;
+    int term_off, rew_off, obs_off, act_off, ray_off, col_off, order_off, n_ray_cols;
+    int max_ep_len;
+    float step_dt, max_ep_len_s;
+    float gx, gy, gz;
+    float rdx, rdy, rdz, ray_max_dist;
+    int ray_yaw_only;
+};
+PlanView imx_plan_view(const imx_plan* p);
+
+// ---- mesh ---------------------------------------------------------------------------------------------------------
+struct MeshView {
+    const float* tri_verts;     // (F,9) xyz of the three corners
+    const int32_t* cell_start;  // (nx*ny + 1)
+    const int32_t* cell_tris;   // (num refs) triangle ids, grouped per cell
+    int nx, ny;
+    float x0, y0, cell, inv_cell;
+    int64_t F;
+};
+struct imx_mesh {
+    MeshView v{};
+    float* d_tri_verts = nullptr;
+    int32_t* d_cell_start = nullptr;
+    int32_t* d_cell_tris = nullptr;
+    int64_t num_refs = 0;
+    int32_t max_refs = 0;
+};
+#define IMX_GRID_TAU 1.0e-3f  // boundary snap tolerance in cell units (see raycast.hip)
+
+// ---- device helpers ------------------------------------------------------------------------------------------------
+#define IMX_DEV static __device__ __forceinline__
+
+IMX_DEV float f_of(int32_t w) { return __int_as_float(w); }
+
+// quat_rotate_inverse (isaaclab/utils/math.py:605-625): a - b + c with
+//   a = v*(2 w^2 - 1), b = cross(q_vec, v)*w*2, c = q_vec*dot(q_vec, v)*2   (same association as the reference)
+IMX_DEV void quat_rotate_inverse(float w, float x, float y, float z, float vx, float vy, float vz, float& ox, float& oy,
+                                 float& oz) {
+    const float s = 2.0f * (w * w) - 1.0f;
+    const float ax = vx * s, ay = vy * s, az = vz * s;
+    const float cx = y * vz - z * vy, cy = z * vx - x * vz, cz = x * vy - y * vx;
+    const float bx = cx * w * 2.0f, by = cy * w * 2.0f, bz = cz * w * 2.0f;
+    const float d = (x * vx + y * vy) + z * vz;  // bmm: sequential dot
+    const float ccx = x * d * 2.0f, ccy = y * d * 2.0f, ccz = z * d * 2.0f;
+    ox = ax - bx + ccx;
+    oy = ay - by + ccy;
+    oz = az - bz + ccz;
+}
+
+// yaw_quat (isaaclab/utils/math.py:521-542) -> (qw, qz) of the yaw-only quaternion (x = y = 0)
+IMX_DEV void yaw_quat_wz(float w, float x, float y, float z, float& yw, float& yz) {
+    const float yaw = atan2f(2.0f * (w * z + x * y), 1.0f - 2.0f * (y * y + z * z));
+    const float s = sinf(yaw * 0.5f), c = cosf(yaw * 0.5f);
+    const float n = fmaxf(sqrtf(c * c + s * s), 1.0e-9f);  // normalize(): x / norm.clamp(min=eps)
+    yw = c / n;
+    yz = s / n;
+}
+
+// quat_apply (isaaclab/utils/math.py:545-564) for a yaw-only quaternion (w,0,0,z):
+//   t = 2*cross(xyz, v);  out = v + w*t + cross(xyz, t)
+IMX_DEV void quat_apply_yaw_only(float w, float z, float vx, float vy, float vz, float& ox, float& oy, float& oz) {
+    const float tx = (0.0f * vz - z * vy) * 2.0f;
+    const float ty = (z * vx - 0.0f * vz) * 2.0f;
+    const float tz = (0.0f * vy - 0.0f * vx) * 2.0f;
+    ox = vx + w * tx + (0.0f * tz - z * ty);
+    oy = vy + w * ty + (z * tx - 0.0f * tz);
+    oz = vz + w * tz + (0.0f * ty - 0.0f * tx);
+}
+
+// full quat_apply
+IMX_DEV void quat_apply(float w, float x, float y, float z, float vx, float vy, float vz, float& ox, float& oy,
+                        float& oz) {
+    const float tx = (y * vz - z * vy) * 2.0f, ty = (z * vx - x * vz) * 2.0f, tz = (x * vy - y * vx) * 2.0f;
+    ox = vx + w * tx + (y * tz - z * ty);
+    oy = vy + w * ty + (z * tx - x * tz);
+    oz = vz + w * tz + (x * ty - y * tx);
+}
+
+// wrap_to_pi (isaaclab/utils/math.py:95-117), torch.remainder semantics
+IMX_DEV float wrap_to_pi(float a) {
+    const float PI = 3.14159265358979323846f, TWO_PI = 6.28318530717958647692f;
+    float m = fmodf(a + PI, TWO_PI);
+    if (m != 0.0f && m < 0.0f) m += TWO_PI;
+    return (m == 0.0f && a > 0.0f) ? PI : m - PI;
+}
+
+IMX_DEV float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+
+// counter-based uniform [0,1): splitmix64 finaliser over (seed, step, element index); 24-bit mantissa like torch.rand
+IMX_DEV float uniform01(uint64_t seed, uint32_t step, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(step + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+

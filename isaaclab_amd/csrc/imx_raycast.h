@@ -1,0 +1,174 @@
+// Device-side closest-hit ray query against the 2-D uniform grid over the terrain mesh.
+//
+// Replaces `wp.mesh_query_ray` as used by raycast_mesh_kernel (reference isaaclab/utils/warp/kernels.py:66).
+// Warp walks a BVH; a terrain is a 2.5-D surface and the height-scanner rays are vertical, so a uniform grid
+// in xy is the better structure here: a vertical ray needs exactly one cell lookup and ~2 triangle tests, all
+// neighbouring rays touch neighbouring cells (L2-friendly), and the build is a counting sort.
+//
+// Per-triangle test: Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection", JCGT 2(1) 2013 -- fp32 edge
+// functions with the fp64 fallback on exact zeros, two-sided, t >= 0.  Same arithmetic as
+// oracle/raycast_oracle.c:woop_f32 (compile with -ffp-contract=off on both sides).
+//
+// Grid membership (host builder in mesh.cpp): with g = (coord - origin) * inv_cell, a triangle spanning
+// [g_lo, g_hi] is listed in cells floor(g_lo + tau) .. ceil(g_hi - tau) - 1 (at least one cell), tau = IMX_GRID_TAU.
+// A ray at g_r looks at floor(g_r), plus the lower neighbour when frac(g_r) < tau and the upper neighbour when
+// frac(g_r) > 1 - tau.  Every triangle whose xy-extent contains the ray is therefore seen, and a height-field
+// mesh aligned with the grid costs 2 triangle references per cell instead of 8.
+#pragma once
+
+#include "imx_internal.h"
+
+struct WoopRay {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+    float ox, oy, oz;
+};
+
+IMX_DEV float pick3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+IMX_DEV WoopRay woop_setup(float ox, float oy, float oz, float dx, float dy, float dz) {
+    WoopRay r;
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    r.kx = r.kz + 1;
+    if (r.kx == 3) r.kx = 0;
+    r.ky = r.kx + 1;
+    if (r.ky == 3) r.ky = 0;
+    const float dkz = pick3(dx, dy, dz, r.kz);
+    if (dkz < 0.0f) {
+        const int t = r.kx;
+        r.kx = r.ky;
+        r.ky = t;
+    }
+    r.Sx = pick3(dx, dy, dz, r.kx) / dkz;
+    r.Sy = pick3(dx, dy, dz, r.ky) / dkz;
+    r.Sz = 1.0f / dkz;
+    r.ox = ox;
+    r.oy = oy;
+    r.oz = oz;
+    return r;
+}
+
+// tv: 9 floats (a, b, c corners)
+IMX_DEV bool woop_hit(const WoopRay& r, const float* __restrict__ tv, float& t) {
+    const float a0 = tv[0] - r.ox, a1 = tv[1] - r.oy, a2 = tv[2] - r.oz;
+    const float b0 = tv[3] - r.ox, b1 = tv[4] - r.oy, b2 = tv[5] - r.oz;
+    const float c0 = tv[6] - r.ox, c1 = tv[7] - r.oy, c2 = tv[8] - r.oz;
+    const float Akz = pick3(a0, a1, a2, r.kz), Bkz = pick3(b0, b1, b2, r.kz), Ckz = pick3(c0, c1, c2, r.kz);
+    const float Ax = pick3(a0, a1, a2, r.kx) - r.Sx * Akz, Ay = pick3(a0, a1, a2, r.ky) - r.Sy * Akz;
+    const float Bx = pick3(b0, b1, b2, r.kx) - r.Sx * Bkz, By = pick3(b0, b1, b2, r.ky) - r.Sy * Bkz;
+    const float Cx = pick3(c0, c1, c2, r.kx) - r.Sx * Ckz, Cy = pick3(c0, c1, c2, r.ky) - r.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return false;
+    t = T * (1.0f / det);
+    return true;
+}
+
+IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, float& best, int32_t& face) {
+    if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
+    const int c = iy * m.nx + ix;
+    const int s = m.cell_start[c], e = m.cell_start[c + 1];
+    for (int k = s; k < e; ++k) {
+        const int32_t f = m.cell_tris[k];
+        float t;
+        if (woop_hit(r, m.tri_verts + (size_t)f * 9, t)) {
+            if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+                best = t;
+                face = f;
+            }
+        }
+    }
+}
+
+// cell column/row of a coordinate plus the optional snapped neighbour (-1/+1, 0 = none)
+IMX_DEV int cell_of(float g, int& nb) {
+    const float fl = floorf(g);
+    const float fr = g - fl;
+    nb = (fr < IMX_GRID_TAU) ? -1 : ((fr > 1.0f - IMX_GRID_TAU) ? 1 : 0);
+    return (int)fl;
+}
+
+// Closest hit with t in [0, max_dist]; returns false on a miss.
+IMX_DEV bool cast_ray(const MeshView& m, float ox, float oy, float oz, float dx, float dy, float dz, float max_dist,
+                      float& t_hit, int32_t& face) {
+    const WoopRay r = woop_setup(ox, oy, oz, dx, dy, dz);
+    float best = max_dist;
+    face = -1;
+    if (dx == 0.0f && dy == 0.0f) {
+        // vertical ray: one cell (+ snapped neighbours)
+        int nbx, nby;
+        const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
+        const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);
+        test_cell(m, r, ix, iy, best, face);
+        if (nbx) test_cell(m, r, ix + nbx, iy, best, face);
+        if (nby) test_cell(m, r, ix, iy + nby, best, face);
+        if (nbx && nby) test_cell(m, r, ix + nbx, iy + nby, best, face);
+    } else {
+        // general ray: 2-D DDA over the grid; every visited cell tests its 3x3 block (covers the tau-shrunk lists)
+        const float gx_lo = m.x0, gy_lo = m.y0, gx_hi = m.x0 + m.nx * m.cell, gy_hi = m.y0 + m.ny * m.cell;
+        float t0 = 0.0f, t1 = max_dist;
+        if (dx != 0.0f) {
+            const float ta = (gx_lo - ox) / dx, tb = (gx_hi - ox) / dx;
+            t0 = fmaxf(t0, fminf(ta, tb));
+            t1 = fminf(t1, fmaxf(ta, tb));
+        } else if (ox < gx_lo || ox > gx_hi) {
+            return false;
+        }
+        if (dy != 0.0f) {
+            const float ta = (gy_lo - oy) / dy, tb = (gy_hi - oy) / dy;
+            t0 = fmaxf(t0, fminf(ta, tb));
+            t1 = fminf(t1, fmaxf(ta, tb));
+        } else if (oy < gy_lo || oy > gy_hi) {
+            return false;
+        }
+        if (t0 > t1) return false;
+        const float px = ox + t0 * dx, py = oy + t0 * dy;
+        int ix = min(max((int)floorf((px - m.x0) * m.inv_cell), 0), m.nx - 1);
+        int iy = min(max((int)floorf((py - m.y0) * m.inv_cell), 0), m.ny - 1);
+        const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+        const float inf = __builtin_huge_valf();
+        float tmx = inf, tmy = inf, tdx = inf, tdy = inf;
+        if (dx != 0.0f) {
+            const float bx = m.x0 + (ix + (sx > 0 ? 1 : 0)) * m.cell;
+            tmx = (bx - ox) / dx;
+            tdx = m.cell / fabsf(dx);
+        }
+        if (dy != 0.0f) {
+            const float by = m.y0 + (iy + (sy > 0 ? 1 : 0)) * m.cell;
+            tmy = (by - oy) / dy;
+            tdy = m.cell / fabsf(dy);
+        }
+        float t_enter = t0;
+        const int max_steps = m.nx + m.ny + 2;
+        for (int step = 0; step < max_steps; ++step) {
+            if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) break;
+            if (t_enter > t1 || (face >= 0 && best < t_enter)) break;
+            for (int jy = -1; jy <= 1; ++jy)
+                for (int jx = -1; jx <= 1; ++jx) test_cell(m, r, ix + jx, iy + jy, best, face);
+            if (tmx < tmy) {
+                t_enter = tmx;
+                tmx += tdx;
+                ix += sx;
+            } else {
+                t_enter = tmy;
+                tmy += tdy;
+                iy += sy;
+            }
+        }
+    }
+    if (face < 0) return false;
+    t_hit = best;
+    return true;
+}

@@ -1,0 +1,270 @@
+// RSL-RL rollout kernels: GAE backward scan + advantage normalisation, fused PPO elementwise loss (fwd/bwd).
+//
+// rsl-rl-lib==2.3.1 is a third-party dependency that is NOT in /root/reference (empty submodule; pinned in
+// source/isaaclab_rl/setup.py:47 and scripts/reinforcement_learning/rsl_rl/train.py:56).  The arithmetic below
+// restates the published upstream v2.3.1 algorithm (rsl_rl/storage/rollout_storage.py::compute_returns,
+// rsl_rl/algorithms/ppo.py::update); PARITY UNPINNED by the reference -- pinned only against oracle/rsl_rl_oracle.py.
+//
+// GAE layout: (T,N) row-major (the (T,N,1) storage tensors), one env per lane, serial over T -- loads/stores of a
+// wave are 64 consecutive floats at every t.
+#include "imx_internal.h"
+
+// Welford/Chan accumulator
+struct Mom {
+    float n, mean, m2;
+};
+IMX_DEV Mom mom_merge(Mom a, Mom b) {
+    Mom r;
+    r.n = a.n + b.n;
+    if (r.n == 0.0f) { r.mean = 0.0f; r.m2 = 0.0f; return r; }
+    const float d = b.mean - a.mean;
+    r.mean = a.mean + d * (b.n / r.n);
+    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+    return r;
+}
+IMX_DEV Mom mom_wave(Mom m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Mom b;
+        b.n = __shfl_xor(m.n, o, 64);
+        b.mean = __shfl_xor(m.mean, o, 64);
+        b.m2 = __shfl_xor(m.m2, o, 64);
+        // keep the merge order symmetric so both partners compute identical bits
+        const bool lo = ((threadIdx.x & o) == 0);
+        m = lo ? mom_merge(m, b) : mom_merge(b, m);
+    }
+    return m;
+}
+
+extern "C" size_t imx_gae_scratch_bytes(int64_t T, int64_t N) {
+    (void)T;
+    const size_t nblk = (size_t)((N + 255) / 256);
+    return (nblk * 3 + 8) * sizeof(float);
+}
+
+// scratch: [0..3*nblk) per-block moments, then {mean, inv_std, ticket(int)} at [3*nblk ..]
+__global__ void __launch_bounds__(256)
+k_gae(int64_t T, int64_t N, const float* __restrict__ rew, const float* __restrict__ val,
+      const uint8_t* __restrict__ dones, const float* __restrict__ last_val, float gamma, float lam,
+      float* __restrict__ ret, float* __restrict__ adv, float* __restrict__ scratch) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < N;
+    Mom m{0.0f, 0.0f, 0.0f};
+    if (live) {
+        float advantage = 0.0f;
+        float next_v = last_val[e];
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const float v = val[t * N + e];
+            const float nnt = 1.0f - (dones[t * N + e] ? 1.0f : 0.0f);
+            const float delta = rew[t * N + e] + nnt * gamma * next_v - v;
+            advantage = delta + nnt * gamma * lam * advantage;
+            const float r = advantage + v;
+            ret[t * N + e] = r;
+            const float a = r - v;  // self.advantages = self.returns - self.values
+            adv[t * N + e] = a;
+            // Welford update
+            m.n += 1.0f;
+            const float d = a - m.mean;
+            m.mean += d / m.n;
+            m.m2 += d * (a - m.mean);
+            next_v = v;
+        }
+    }
+    __shared__ Mom sm[4];
+    m = mom_wave(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Mom b = sm[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) b = mom_merge(b, sm[w]);
+        scratch[3 * blockIdx.x + 0] = b.n;
+        scratch[3 * blockIdx.x + 1] = b.mean;
+        scratch[3 * blockIdx.x + 2] = b.m2;
+    }
+}
+
+// every block merges the per-block moments in the same fixed order (a few hundred entries) and normalises its slice
+__global__ void __launch_bounds__(256)
+k_adv_normalize(int64_t total, int nblk, const float* __restrict__ scratch, float* __restrict__ adv) {
+    __shared__ float s_mean, s_inv;
+    if (threadIdx.x == 0) {
+        Mom b{0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < nblk; ++i) {
+            Mom c{scratch[3 * i], scratch[3 * i + 1], scratch[3 * i + 2]};
+            b = mom_merge(b, c);
+        }
+        const float var = b.n > 1.0f ? b.m2 / (b.n - 1.0f) : 0.0f;  // torch.std: unbiased
+        s_mean = b.mean;
+        s_inv = 1.0f / (sqrtf(var) + 1.0e-8f);
+    }
+    __syncthreads();
+    const float mean = s_mean, inv = s_inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = (adv[i] - mean) * inv;
+}
+
+extern "C" int imx_gae(int64_t T, int64_t N, const float* rew, const float* val, const uint8_t* dones,
+                       const float* last_val, float gamma, float lam, int normalize, float* ret, float* adv,
+                       void* scratch, imx_stream_t stream) {
+    IMX_REQUIRE(T > 0 && N > 0, "imx_gae: empty rollout (T=%lld N=%lld)", (long long)T, (long long)N);
+    IMX_REQUIRE(rew && val && dones && last_val && ret && adv && scratch, "imx_gae: null argument");
+    const unsigned nblk = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_gae, dim3(nblk), dim3(256), 0, (hipStream_t)stream, T, N, rew, val, dones, last_val, gamma, lam,
+                       ret, adv, (float*)scratch);
+    IMX_HIP(hipGetLastError());
+    if (normalize) {
+        const int64_t total = T * N;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_adv_normalize, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, (int)nblk,
+                           (const float*)scratch, adv);
+        IMX_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- PPO loss
+// Per sample i (minibatch of M), action dim A, sigma broadcast over the batch when sigma_stride == 0:
+//   logp   = sum_a( -(a-mu)^2/(2 s^2) - log s - 0.5 log(2 pi) )          Normal.log_prob(...).sum(-1)
+//   ent    = sum_a( 0.5 + 0.5 log(2 pi) + log s )                         Normal.entropy().sum(-1)
+//   kl     = sum_a( log(s/so + 1e-5) + (so^2 + (muo-mu)^2)/(2 s^2) - 0.5 )
+//   ratio  = exp(logp - old_logp); surrogate = max(-adv*ratio, -adv*clamp(ratio, 1-c, 1+c))
+//   value  = clipped: max((v-R)^2, (vo + clamp(v-vo,-c,c) - R)^2) ; else (R-v)^2
+// out4 = means over the minibatch.
+#define IMX_HALF_LOG_2PI 0.91893853320467274178f
+
+extern "C" size_t imx_ppo_scratch_bytes(int64_t M) { return ((size_t)((M + 255) / 256) * 4 + 8) * sizeof(float); }
+
+__global__ void __launch_bounds__(256)
+k_ppo_fwd(int64_t M, int A, const float* __restrict__ mu, const float* __restrict__ sigma, int sigma_stride,
+          const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+          const float* __restrict__ old_sigma, const float* __restrict__ adv, const float* __restrict__ ret,
+          const float* __restrict__ val, const float* __restrict__ old_val, float clip, int clipped_value,
+          float* __restrict__ part) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sur = 0.0f, vl = 0.0f, ent = 0.0f, kl = 0.0f;
+    if (i < M) {
+        float logp = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
+            const float d = act[i * A + a] - m;
+            const float ls = logf(s);
+            logp += -(d * d) / (2.0f * s * s) - ls - IMX_HALF_LOG_2PI;
+            ent += 0.5f + IMX_HALF_LOG_2PI + ls;
+            if (old_mu) {
+                const float mo = old_mu[i * A + a], so = old_sigma[i * A + a];
+                const float dm = mo - m;
+                kl += logf(s / so + 1.0e-5f) + (so * so + dm * dm) / (2.0f * s * s) - 0.5f;
+            }
+        }
+        const float ratio = expf(logp - old_logp[i]);
+        const float ad = adv[i];
+        const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+        sur = fmaxf(s1, s2);
+        const float v = val[i], R = ret[i];
+        if (clipped_value) {
+            const float vo = old_val[i];
+            const float vc = vo + fminf(fmaxf(v - vo, -clip), clip);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            vl = fmaxf(l1, l2);
+        } else {
+            vl = (R - v) * (R - v);
+        }
+    }
+    __shared__ float sm[4][4];
+    float r4[4] = {sur, vl, ent, kl};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = r4[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[4 * blockIdx.x + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+__global__ void k_ppo_finish(int nblk, float inv_m, const float* __restrict__ part, float* __restrict__ out4) {
+    const int q = threadIdx.x;
+    if (q >= 4) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += part[4 * b + q];
+    out4[q] = s * inv_m;
+}
+
+// d/d(mu, sigma, value) of  mean(sur) + vcoef*mean(vl) - ecoef*mean(ent), times grad_scale (the upstream grad)
+__global__ void __launch_bounds__(256)
+k_ppo_bwd(int64_t M, int A, const float* __restrict__ mu, const float* __restrict__ sigma, int sigma_stride,
+          const float* __restrict__ act, const float* __restrict__ old_logp, const float* __restrict__ adv,
+          const float* __restrict__ ret, const float* __restrict__ val, const float* __restrict__ old_val, float clip,
+          int clipped_value, float vcoef, float ecoef, float gscale, float* __restrict__ dmu,
+          float* __restrict__ dsigma, float* __restrict__ dval) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float inv_m = gscale / (float)M;
+    float logp = 0.0f;
+    for (int a = 0; a < A; ++a) {
+        const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
+        const float d = act[i * A + a] - m;
+        logp += -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI;
+    }
+    const float ratio = expf(logp - old_logp[i]);
+    const float ad = adv[i];
+    const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    // torch.max picks the first argument's gradient on ties? (max backward splits evenly on ties; ties only when
+    // ratio is inside the clip range where both branches have the same derivative -ad*ratio)
+    float dsur_dlogp;
+    if (s1 >= s2) dsur_dlogp = -ad * ratio;
+    else dsur_dlogp = (ratio > 1.0f - clip && ratio < 1.0f + clip) ? -ad * ratio : 0.0f;
+    const float g = dsur_dlogp * inv_m;
+    for (int a = 0; a < A; ++a) {
+        const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
+        const float d = act[i * A + a] - m;
+        dmu[i * A + a] = g * (d / (s * s));
+        // dlogp/ds = d^2/s^3 - 1/s ; dent/ds = 1/s
+        dsigma[i * A + a] = g * ((d * d) / (s * s * s) - 1.0f / s) - ecoef * inv_m / s;
+    }
+    const float v = val[i], R = ret[i];
+    float dv;
+    if (clipped_value) {
+        const float vo = old_val[i];
+        const float dlt = v - vo;
+        const float vc = vo + fminf(fmaxf(dlt, -clip), clip);
+        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+        if (l1 >= l2) dv = 2.0f * (v - R);
+        else dv = (dlt > -clip && dlt < clip) ? 2.0f * (vc - R) : 0.0f;
+    } else {
+        dv = -2.0f * (R - v);
+    }
+    dval[i] = vcoef * dv * inv_m;
+}
+
+extern "C" int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu, const float* sigma, const float* act,
+                                const float* old_logp, const float* old_mu, const float* old_sigma, const float* adv,
+                                const float* ret, const float* val, const float* old_val, float clip, int clipped_value,
+                                float* out4, void* scratch, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && A > 0 && A <= 4096, "imx_ppo_loss_fwd: bad sizes M=%lld A=%lld", (long long)M, (long long)A);
+    IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && out4 && scratch, "imx_ppo_loss_fwd: null argument");
+    IMX_REQUIRE(!clipped_value || old_val, "imx_ppo_loss_fwd: clipped value loss needs old values");
+    IMX_REQUIRE((old_mu == nullptr) == (old_sigma == nullptr), "imx_ppo_loss_fwd: old_mu/old_sigma must come together");
+    const unsigned nblk = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(k_ppo_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma, (int)A, act, old_logp,
+                       old_mu, old_sigma, adv, ret, val, old_val, clip, clipped_value, (float*)scratch);
+    hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)nblk, 1.0f / (float)M,
+                       (const float*)scratch, out4);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu, const float* sigma, const float* act,
+                                const float* old_logp, const float* adv, const float* ret, const float* val,
+                                const float* old_val, float clip, int clipped_value, float vcoef, float ecoef,
+                                float gscale, float* dmu, float* dsigma, float* dval, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && A > 0, "imx_ppo_loss_bwd: bad sizes");
+    IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && dmu && dsigma && dval, "imx_ppo_loss_bwd: null argument");
+    IMX_REQUIRE(!clipped_value || old_val, "imx_ppo_loss_bwd: clipped value loss needs old values");
+    hipLaunchKernelGGL(k_ppo_bwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma,
+                       (int)A, act, old_logp, adv, ret, val, old_val, clip, clipped_value, vcoef, ecoef, gscale, dmu, dsigma,
+                       dval);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,700 @@
+// Post-physics env-step kernels (gfx950): action affine, terminations + rewards + reset bookkeeping, observations.
+//
+// Layout: one environment per lane ("env-per-lane") for the reduction-shaped work (terminations, rewards: every term
+// is a small per-env reduction over joints/bodies), one OUTPUT ELEMENT per lane for the observation matrix so that
+// the (N,D) row-major store is perfectly coalesced.  Term tables are wave-uniform, so the interpreter's switch is a
+// scalar branch; per-term constants come through the scalar cache.  All arithmetic is fp32 in the reference's
+// association order (compile with -ffp-contract=off).
+#include "imx_internal.h"
+#include "imx_raycast.h"
+
+// ------------------------------------------------------------------------------------------------- helpers
+IMX_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+IMX_DEV int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// max over history of the force norm on body b (rewards.py:266, terminations.py:157)
+IMX_DEV float max_hist_force(const float* __restrict__ F, int64_t e, int H, int B, int b) {
+    float m = -__builtin_huge_valf();
+    for (int h = 0; h < H; ++h) {
+        const float* f = F + (((size_t)e * H + h) * B + b) * 3;
+        m = fmaxf(m, norm3(f[0], f[1], f[2]));
+    }
+    return m;
+}
+
+// scratch layout for k_term_rew (all sizes in 4-byte words, nw = number of waves = ceil(N/64))
+//   [0, nw*KA)               float  per-wave partial sums of episode_sums over reset envs
+//   [.., + nw*NT)            int    per-wave counts of term_dones over reset envs
+//   [.., + nw)               int    per-wave reset counts
+//   [.., + nw*64)            int    per-wave compacted local reset ids
+struct StepScratch {
+    float* log_part;
+    int* term_part;
+    int* wave_cnt;
+    int* ids_local;
+};
+static inline size_t step_scratch_words(int64_t N, int KA, int NT) {
+    const size_t nw = (size_t)((N + 63) / 64);
+    return nw * KA + nw * NT + nw + nw * 64;
+}
+static inline StepScratch carve(void* base, int64_t N, int KA, int NT) {
+    const size_t nw = (size_t)((N + 63) / 64);
+    StepScratch s;
+    s.log_part = (float*)base;
+    s.term_part = (int*)(s.log_part + nw * KA);
+    s.wave_cnt = s.term_part + nw * NT;
+    s.ids_local = s.wave_cnt + nw;
+    return s;
+}
+
+extern "C" size_t imx_plan_scratch_bytes(const imx_plan_t* plan, int64_t num_envs) {
+    if (!plan || num_envs <= 0) return 0;
+    return 4 * step_scratch_words(num_envs, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1) + 256;
+}
+
+// ------------------------------------------------------------------------------------------------- action affine
+// ActionManager.process_action (action_manager.py:318-337): prev <- cur; cur <- a; per term
+// processed = raw*scale + offset [clamp]  (joint_actions.py:130-139)
+__global__ void k_action(PlanView P, int64_t N, const float* __restrict__ actions, float pre_clip, imx_state_t S,
+                         imx_buffers_t Bf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * P.A) return;
+    const int64_t e = i / P.A;
+    const int c = (int)(i - e * P.A);
+    float a = actions[i];
+    if (pre_clip < __builtin_huge_valf()) a = fminf(fmaxf(a, -pre_clip), pre_clip);  // torch.clamp
+    Bf.prev_action[i] = Bf.action[i];
+    Bf.action[i] = a;
+    // find the term that owns column c (few terms; uniform loop)
+    for (int k = 0; k < P.nact; ++k) {
+        const int32_t* r = P.w + P.act_off + k * IMX_REC_WORDS;
+        const int o = r[IMX_R_OUT], d = r[IMX_R_DIM];
+        if (c < o || c >= o + d) continue;
+        const int j = c - o;
+        const int flags = r[IMX_R_FLAGS];
+        const float scale = r[IMX_R_AUX0] ? f_of(P.w[r[IMX_R_AUX0] + j]) : f_of(r[IMX_R_P0]);
+        float offset = r[IMX_R_AUX1] ? f_of(P.w[r[IMX_R_AUX1] + j]) : f_of(r[IMX_R_P1]);
+        const int jid = P.w[r[IMX_R_IDS_OFF] + j];
+        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) offset = S.default_joint_pos[e * P.J + jid];
+        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) offset = S.default_joint_vel[e * P.J + jid];
+        float v = a * scale + offset;
+        if (flags & IMX_F_ACT_CLIP) {
+            const float lo = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j]), hi = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j + 1]);
+            v = fminf(fmaxf(v, lo), hi);
+        }
+        Bf.processed_action[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- terminations + rewards
+__global__ void __launch_bounds__(256)
+k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < N;
+    const int64_t ec = live ? e : N - 1;  // clamp: dead lanes compute on a valid env, never store
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int J = P.J, Bn = P.B, H = P.H, A = P.A;
+    const int32_t* __restrict__ W = P.w;
+
+    // -- root frame (ArticulationData.root_lin_vel_b / root_ang_vel_b / projected_gravity_b)
+    const float qw = S.root_quat_w[ec * 4 + 0], qx = S.root_quat_w[ec * 4 + 1], qy = S.root_quat_w[ec * 4 + 2],
+                qz = S.root_quat_w[ec * 4 + 3];
+    const float lwx = S.root_lin_vel_w[ec * 3], lwy = S.root_lin_vel_w[ec * 3 + 1], lwz = S.root_lin_vel_w[ec * 3 + 2];
+    const float awx = S.root_ang_vel_w[ec * 3], awy = S.root_ang_vel_w[ec * 3 + 1], awz = S.root_ang_vel_w[ec * 3 + 2];
+    float lbx, lby, lbz, abx, aby, abz, pgx, pgy, pgz;
+    quat_rotate_inverse(qw, qx, qy, qz, lwx, lwy, lwz, lbx, lby, lbz);
+    quat_rotate_inverse(qw, qx, qy, qz, awx, awy, awz, abx, aby, abz);
+    quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, pgx, pgy, pgz);
+
+    // -- episode counter (manager_based_rl_env.py:200)
+    const int64_t ep = Bf.episode_length_buf[ec] + 1;
+
+    // -- TerminationManager.compute (termination_manager.py:151-174)
+    uint32_t term_bits = 0;
+    bool terminated = false, truncated = false;
+    for (int k = 0; k < P.nterm; ++k) {
+        const int32_t* r = W + P.term_off + k * IMX_REC_WORDS;
+        const int op = r[IMX_R_OP];
+        const int32_t* ids = W + r[IMX_R_IDS_OFF];
+        const int n = r[IMX_R_NIDS];
+        const float p0 = f_of(r[IMX_R_P0]), p1 = f_of(r[IMX_R_P1]);
+        bool v = false;
+        switch (op) {
+            case IMX_T_TIME_OUT: v = ep >= (int64_t)P.max_ep_len; break;
+            case IMX_T_ILLEGAL_CONTACT:
+                for (int i = 0; i < n; ++i) v = v || (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > p0);
+                break;
+            case IMX_T_JOINT_POS_MANUAL_LIMIT:
+                for (int i = 0; i < n; ++i) {
+                    const float q = S.joint_pos[ec * J + ids[i]];
+                    v = v || (q > p1) || (q < p0);
+                }
+                break;
+            case IMX_T_BAD_ORIENTATION: v = fabsf(acosf(-pgz)) > p0; break;
+            case IMX_T_ROOT_HEIGHT_BELOW_MIN: v = S.root_pos_w[ec * 3 + 2] < p0; break;
+            case IMX_T_JOINT_VEL_LIMIT:
+                for (int i = 0; i < n; ++i)
+                    v = v || (fabsf(S.joint_vel[ec * J + ids[i]]) > S.soft_joint_vel_limits[ec * J + ids[i]]);
+                break;
+            case IMX_T_JOINT_VEL_MANUAL_LIMIT:
+                for (int i = 0; i < n; ++i) v = v || (fabsf(S.joint_vel[ec * J + ids[i]]) > p0);
+                break;
+            case IMX_T_JOINT_EFFORT_LIMIT:  // torch.isclose(computed, applied): |a-b| <= atol + rtol*|b|
+                for (int i = 0; i < n; ++i) {
+                    const float a = S.computed_torque[ec * J + ids[i]], b = S.applied_torque[ec * J + ids[i]];
+                    v = v || (fabsf(a - b) <= 1.0e-8f + 1.0e-5f * fabsf(b));
+                }
+                break;
+            case IMX_T_TERRAIN_OUT_OF_BOUNDS:
+                v = (fabsf(S.root_pos_w[ec * 3]) > p0) || (fabsf(S.root_pos_w[ec * 3 + 1]) > p1);
+                break;
+            case IMX_T_EXTERNAL: v = S.ext_term[ec * (int64_t)W[IMX_H_NEXT_TERM] + r[IMX_R_AUX0]] != 0; break;
+            default: break;
+        }
+        if (r[IMX_R_WEIGHT]) truncated = truncated || v; else terminated = terminated || v;
+        term_bits |= v ? (1u << k) : 0u;
+        if (live) Bf.term_dones[(size_t)k * N + e] = v ? 1 : 0;
+    }
+    const bool reset = live && (terminated || truncated);
+
+    // -- RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; reward += value; sums += value
+    const float dt = P.step_dt;
+    float reward = 0.0f;
+    const float cmdx = P.CMD > 0 ? S.command[ec * P.CMD + 0] : 0.0f;
+    const float cmdy = P.CMD > 1 ? S.command[ec * P.CMD + 1] : 0.0f;
+    const float cmdz = P.CMD > 2 ? S.command[ec * P.CMD + 2] : 0.0f;
+    int next_all = 0;  // reward-manager term index cursor: terms skipped for zero weight still own a slot
+    for (int k = 0; k <= P.nrew; ++k) {
+        const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
+        const int idx = (k < P.nrew) ? r[IMX_R_OUT] : P.nrew_all;
+        // slots of skipped terms: episode sum stays as is (0 since reset), but it is part of the reset/log pass
+        for (; next_all < idx; ++next_all) {
+            const float es = live ? Bf.episode_sums[(size_t)next_all * N + e] : 0.0f;
+            const float part = wave_sum(reset ? es : 0.0f);
+            if (lane == 0) sc.log_part[wave * P.nrew_all + next_all] = part;
+            if (reset) Bf.episode_sums[(size_t)next_all * N + e] = 0.0f;
+        }
+        if (k == P.nrew) break;
+        next_all = idx + 1;
+        const int op = r[IMX_R_OP];
+        const int32_t* ids = W + r[IMX_R_IDS_OFF];
+        const int n = r[IMX_R_NIDS];
+        const float p0 = f_of(r[IMX_R_P0]);
+        float f = 0.0f;
+        switch (op) {
+            case IMX_W_IS_ALIVE: f = terminated ? 0.0f : 1.0f; break;
+            case IMX_W_IS_TERMINATED: f = terminated ? 1.0f : 0.0f; break;
+            case IMX_W_IS_TERMINATED_TERM: {
+                float s = 0.0f;
+                for (int i = 0; i < n; ++i) s += ((term_bits >> ids[i]) & 1u) ? 1.0f : 0.0f;
+                f = s * (truncated ? 0.0f : 1.0f);
+            } break;
+            case IMX_W_LIN_VEL_Z_L2: f = lbz * lbz; break;
+            case IMX_W_ANG_VEL_XY_L2: f = abx * abx + aby * aby; break;
+            case IMX_W_FLAT_ORIENTATION_L2: f = pgx * pgx + pgy * pgy; break;
+            case IMX_W_BASE_HEIGHT_L2: { const float d = S.root_pos_w[ec * 3 + 2] - p0; f = d * d; } break;
+            case IMX_W_JOINT_TORQUES_L2:
+                for (int i = 0; i < n; ++i) { const float x = S.applied_torque[ec * J + ids[i]]; f += x * x; }
+                break;
+            case IMX_W_JOINT_VEL_L1:
+                for (int i = 0; i < n; ++i) f += fabsf(S.joint_vel[ec * J + ids[i]]);
+                break;
+            case IMX_W_JOINT_VEL_L2:
+                for (int i = 0; i < n; ++i) { const float x = S.joint_vel[ec * J + ids[i]]; f += x * x; }
+                break;
+            case IMX_W_JOINT_ACC_L2:
+                for (int i = 0; i < n; ++i) { const float x = S.joint_acc[ec * J + ids[i]]; f += x * x; }
+                break;
+            case IMX_W_JOINT_DEVIATION_L1:
+                for (int i = 0; i < n; ++i)
+                    f += fabsf(S.joint_pos[ec * J + ids[i]] - S.default_joint_pos[ec * J + ids[i]]);
+                break;
+            case IMX_W_JOINT_POS_LIMITS:
+                for (int i = 0; i < n; ++i) {
+                    const float q = S.joint_pos[ec * J + ids[i]];
+                    const float lo = S.soft_joint_pos_limits[(ec * J + ids[i]) * 2],
+                                hi = S.soft_joint_pos_limits[(ec * J + ids[i]) * 2 + 1];
+                    float o = -fminf(q - lo, 0.0f);
+                    o += fmaxf(q - hi, 0.0f);
+                    f += o;
+                }
+                break;
+            case IMX_W_JOINT_VEL_LIMITS:
+                for (int i = 0; i < n; ++i) {
+                    const float o = fabsf(S.joint_vel[ec * J + ids[i]]) - S.soft_joint_vel_limits[ec * J + ids[i]] * p0;
+                    f += fminf(fmaxf(o, 0.0f), 1.0f);
+                }
+                break;
+            case IMX_W_APPLIED_TORQUE_LIMITS:
+                for (int i = 0; i < n; ++i)
+                    f += fabsf(S.applied_torque[ec * J + ids[i]] - S.computed_torque[ec * J + ids[i]]);
+                break;
+            case IMX_W_ACTION_RATE_L2:
+                for (int i = 0; i < A; ++i) { const float d = Bf.action[ec * A + i] - Bf.prev_action[ec * A + i]; f += d * d; }
+                break;
+            case IMX_W_ACTION_L2:
+                for (int i = 0; i < A; ++i) { const float a = Bf.action[ec * A + i]; f += a * a; }
+                break;
+            case IMX_W_UNDESIRED_CONTACTS:
+                for (int i = 0; i < n; ++i) f += (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > p0) ? 1.0f : 0.0f;
+                break;
+            case IMX_W_CONTACT_FORCES:
+                for (int i = 0; i < n; ++i) f += fmaxf(max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) - p0, 0.0f);
+                break;
+            case IMX_W_TRACK_LIN_VEL_XY_EXP: {
+                const float ex = cmdx - lbx, ey = cmdy - lby;
+                f = expf(-(ex * ex + ey * ey) / p0);  // p0 = std**2
+            } break;
+            case IMX_W_TRACK_ANG_VEL_Z_EXP: { const float ez = cmdz - abz; f = expf(-(ez * ez) / p0); } break;
+            case IMX_W_FEET_AIR_TIME: {
+                // first_contact = (cct > 0) * (cct < dt + abs_tol); p1 = float32(step_dt + 1e-8)
+                const float p1 = f_of(r[IMX_R_P1]);
+                for (int i = 0; i < n; ++i) {
+                    const float cct = S.current_contact_time[ec * Bn + ids[i]];
+                    const float fc = (cct > 0.0f && cct < p1) ? 1.0f : 0.0f;
+                    f += (S.last_air_time[ec * Bn + ids[i]] - p0) * fc;
+                }
+                f *= (sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f) ? 1.0f : 0.0f;
+            } break;
+            case IMX_W_FEET_AIR_TIME_POSITIVE_BIPED: {
+                int n_contact = 0;
+                float mn = __builtin_huge_valf();
+                for (int i = 0; i < n; ++i) n_contact += (S.current_contact_time[ec * Bn + ids[i]] > 0.0f) ? 1 : 0;
+                for (int i = 0; i < n; ++i) {
+                    const float ct = S.current_contact_time[ec * Bn + ids[i]], at = S.current_air_time[ec * Bn + ids[i]];
+                    const float in_mode = (ct > 0.0f) ? ct : at;
+                    mn = fminf(mn, (n_contact == 1) ? in_mode : 0.0f);
+                }
+                f = fminf(mn, p0);
+                f *= (sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f) ? 1.0f : 0.0f;
+            } break;
+            case IMX_W_FEET_SLIDE: {
+                const int32_t* ids2 = W + r[IMX_R_IDS2_OFF];
+                for (int i = 0; i < n; ++i) {
+                    const float c = (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > 1.0f) ? 1.0f : 0.0f;
+                    const float* v = S.body_lin_vel_w + ((size_t)ec * P.NB + ids2[i]) * 3;
+                    f += sqrtf(v[0] * v[0] + v[1] * v[1]) * c;
+                }
+            } break;
+            case IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {
+                float yw, yz, vx, vy, vz;
+                yaw_quat_wz(qw, qx, qy, qz, yw, yz);
+                quat_rotate_inverse(yw, 0.0f, 0.0f, yz, lwx, lwy, lwz, vx, vy, vz);
+                const float ex = cmdx - vx, ey = cmdy - vy;
+                f = expf(-(ex * ex + ey * ey) / p0);
+            } break;
+            case IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP: { const float ez = cmdz - awz; f = expf(-(ez * ez) / p0); } break;
+            case IMX_W_JOINT_POS_TARGET_L2:
+                for (int i = 0; i < n; ++i) { const float d = wrap_to_pi(S.joint_pos[ec * J + ids[i]]) - p0; f += d * d; }
+                break;
+            case IMX_W_EXTERNAL: f = S.ext_reward[ec * (int64_t)W[IMX_H_NEXT_REW] + r[IMX_R_AUX0]]; break;
+            default: break;
+        }
+        const float value = f * f_of(r[IMX_R_WEIGHT]) * dt;
+        reward += value;
+        const float es = (live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f) + value;
+        if (live) {
+            Bf.step_reward[(size_t)e * P.nrew_all + idx] = value / dt;
+            Bf.episode_sums[(size_t)idx * N + e] = reset ? 0.0f : es;
+        }
+        // RewardManager.reset log (reward_manager.py:115-121): mean over reset envs of the episodic sum
+        const float part = wave_sum(reset ? es : 0.0f);
+        if (lane == 0) sc.log_part[wave * P.nrew_all + idx] = part;
+    }
+
+    // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
+    if (live) {
+        Bf.reward_buf[e] = reward;
+        Bf.terminated[e] = terminated ? 1 : 0;
+        Bf.truncated[e] = truncated ? 1 : 0;
+        Bf.reset_buf[e] = reset ? 1 : 0;
+        Bf.episode_length_buf[e] = reset ? 0 : ep;
+        if (reset)
+            for (int i = 0; i < A; ++i) {  // ActionManager.reset (action_manager.py:306-316)
+                Bf.action[e * A + i] = 0.0f;
+                Bf.prev_action[e * A + i] = 0.0f;
+            }
+    }
+    // TerminationManager.reset log (termination_manager.py:142-144): count_nonzero(term_dones[reset ids])
+    for (int k = 0; k < P.nterm; ++k) {
+        const int c = wave_sum_i((reset && ((term_bits >> k) & 1u)) ? 1 : 0);
+        if (lane == 0) sc.term_part[wave * P.nterm + k] = c;
+    }
+    // ordered compaction inside the wave: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
+    const unsigned long long ballot = __ballot(reset);
+    const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (reset) sc.ids_local[wave * 64 + before] = (int)(e & 63);
+    if (lane == 0) sc.wave_cnt[wave] = __popcll(ballot);
+
+    // -- last block finishes: ordered concatenation of the per-wave id lists + log reductions (deterministic order)
+    __shared__ int s_last;
+    __shared__ float s_red[256];
+    __shared__ int s_scan[256];
+    __threadfence();  // release this block's partials (agent scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&Bf.counters[1], 1);
+        s_last = (ticket == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire the other blocks' partials
+    const int nw = (int)((N + 63) / 64);
+    const int T = blockDim.x;
+    const int t = threadIdx.x;
+    // exclusive scan of wave counts: thread t owns waves [t*chunk, (t+1)*chunk)
+    const int chunk = (nw + T - 1) / T;
+    int local = 0;
+    for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) local += __builtin_nontemporal_load(&sc.wave_cnt[w]);
+    s_scan[t] = local;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < T; ++i) { const int c = s_scan[i]; s_scan[i] = run; run += c; }
+        Bf.counters[0] = run;  // number of reset envs
+        Bf.counters[1] = 0;    // re-arm the ticket
+        Bf.counters[2] += 1;   // step counter (keys the observation-noise stream)
+        s_last = run;
+    }
+    __syncthreads();
+    const int total = s_last;
+    int off = s_scan[t];
+    for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
+        const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
+        for (int j = 0; j < c; ++j)
+            Bf.reset_env_ids[off + j] = (int64_t)w * 64 + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
+        off += c;
+    }
+    if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
+        for (int k = 0; k < P.nrew_all; ++k) {
+            float s = 0.0f;
+            for (int w = t; w < nw; w += T) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
+            s_red[t] = s;
+            __syncthreads();
+            for (int o = T >> 1; o > 0; o >>= 1) {
+                if (t < o) s_red[t] += s_red[t + o];
+                __syncthreads();
+            }
+            if (t == 0) Bf.log_out[k] = s_red[0] / (float)total / P.max_ep_len_s;
+            __syncthreads();
+        }
+        for (int k = 0; k < P.nterm; ++k) {
+            int s = 0;
+            for (int w = t; w < nw; w += T) s += __builtin_nontemporal_load(&sc.term_part[(size_t)w * P.nterm + k]);
+            s_scan[t] = s;
+            __syncthreads();
+            for (int o = T >> 1; o > 0; o >>= 1) {
+                if (t < o) s_scan[t] += s_scan[t + o];
+                __syncthreads();
+            }
+            if (t == 0) Bf.log_out[P.nrew_all + k] = (float)s_scan[0];
+            __syncthreads();
+        }
+        if (t == 0) Bf.log_out[P.nrew_all + P.nterm] = (float)total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- observations
+// One block = EB consecutive envs.  Phase 1 (EB lanes): per-env derived state into LDS (root-frame vectors, yaw
+// quaternion of the height-scanner).  Phase 2: one output element per lane, ray columns first (heavy work is
+// contiguous in the wave), results stored straight to obs[e*D + c] -- consecutive lanes, consecutive addresses.
+#define IMX_ENV_S 24  // floats of per-env LDS state
+template <int EB>
+__global__ void __launch_bounds__(256)
+k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ noise_u,
+      uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
+    __shared__ float es[EB][IMX_ENV_S];
+    const int64_t e0 = (int64_t)blockIdx.x * EB;
+    const int32_t* __restrict__ W = P.w;
+    if (threadIdx.x < EB) {
+        const int64_t e = min(e0 + threadIdx.x, N - 1);
+        float* s = es[threadIdx.x];
+        const float qw = S.root_quat_w[e * 4], qx = S.root_quat_w[e * 4 + 1], qy = S.root_quat_w[e * 4 + 2],
+                    qz = S.root_quat_w[e * 4 + 3];
+        quat_rotate_inverse(qw, qx, qy, qz, S.root_lin_vel_w[e * 3], S.root_lin_vel_w[e * 3 + 1],
+                            S.root_lin_vel_w[e * 3 + 2], s[0], s[1], s[2]);
+        quat_rotate_inverse(qw, qx, qy, qz, S.root_ang_vel_w[e * 3], S.root_ang_vel_w[e * 3 + 1],
+                            S.root_ang_vel_w[e * 3 + 2], s[3], s[4], s[5]);
+        quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, s[6], s[7], s[8]);
+        s[9] = S.root_pos_w[e * 3]; s[10] = S.root_pos_w[e * 3 + 1]; s[11] = S.root_pos_w[e * 3 + 2];
+        s[12] = qw; s[13] = qx; s[14] = qy; s[15] = qz;
+        float yw = 1.0f, yz = 0.0f;
+        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, yw, yz);
+        s[16] = yw; s[17] = yz;
+    }
+    __syncthreads();
+    const uint32_t step = (uint32_t)Bf.counters[2];
+    const int D = P.D, J = P.J;
+    const int total = EB * D;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        // work order: all ray columns of all EB envs first, then the rest
+        int el, c;
+        const int nray = EB * P.n_ray_cols;
+        if (i < nray) {
+            el = i / P.n_ray_cols;
+            c = W[P.order_off + (i - el * P.n_ray_cols)];
+        } else {
+            const int rem = i - nray, np = D - P.n_ray_cols;
+            el = rem / np;
+            c = W[P.order_off + P.n_ray_cols + (rem - el * np)];
+        }
+        const int64_t e = e0 + el;
+        if (e >= N) continue;
+        const float* s = es[el];
+        const int cr = W[P.col_off + c];
+        const int32_t* r = W + P.obs_off + (cr >> 16) * IMX_REC_WORDS;
+        const int j = cr & 0xFFFF;
+        const int op = r[IMX_R_OP];
+        const int flags = r[IMX_R_FLAGS];
+        float v = 0.0f;
+        switch (op) {
+            case IMX_O_BASE_POS_Z: v = s[11]; break;
+            case IMX_O_BASE_LIN_VEL: v = s[0 + j]; break;
+            case IMX_O_BASE_ANG_VEL: v = s[3 + j]; break;
+            case IMX_O_PROJECTED_GRAVITY: v = s[6 + j]; break;
+            case IMX_O_ROOT_POS_W: v = s[9 + j] - S.env_origins[e * 3 + j]; break;
+            case IMX_O_ROOT_QUAT_W: v = (flags & IMX_F_QUAT_UNIQUE) && s[12] < 0.0f ? -s[12 + j] : s[12 + j]; break;
+            case IMX_O_ROOT_LIN_VEL_W: v = S.root_lin_vel_w[e * 3 + j]; break;
+            case IMX_O_ROOT_ANG_VEL_W: v = S.root_ang_vel_w[e * 3 + j]; break;
+            case IMX_O_JOINT_POS: v = S.joint_pos[e * J + W[r[IMX_R_IDS_OFF] + j]]; break;
+            case IMX_O_JOINT_POS_REL: {
+                const int jid = W[r[IMX_R_IDS_OFF] + j];
+                v = S.joint_pos[e * J + jid] - S.default_joint_pos[e * J + jid];
+            } break;
+            case IMX_O_JOINT_POS_LIMIT_NORMALIZED: {  // scale_transform (utils/math.py:22-40)
+                const int jid = W[r[IMX_R_IDS_OFF] + j];
+                const float lo = S.soft_joint_pos_limits[(e * J + jid) * 2], hi = S.soft_joint_pos_limits[(e * J + jid) * 2 + 1];
+                const float offset = (lo + hi) * 0.5f;
+                v = 2.0f * (S.joint_pos[e * J + jid] - offset) / (hi - lo);
+            } break;
+            case IMX_O_JOINT_VEL: v = S.joint_vel[e * J + W[r[IMX_R_IDS_OFF] + j]]; break;
+            case IMX_O_JOINT_VEL_REL: {
+                const int jid = W[r[IMX_R_IDS_OFF] + j];
+                v = S.joint_vel[e * J + jid] - S.default_joint_vel[e * J + jid];
+            } break;
+            case IMX_O_LAST_ACTION: v = Bf.action[e * P.A + j]; break;
+            case IMX_O_GENERATED_COMMANDS: v = S.command[e * P.CMD + j]; break;
+            case IMX_O_EXTERNAL: v = S.ext_obs[e * (int64_t)W[IMX_H_NEXT_OBS] + r[IMX_R_AUX0] + j]; break;
+            case IMX_O_HEIGHT_SCAN: {
+                // RayCaster._update_buffers_impl (ray_caster.py:242-260) + height_scan (observations.py:165-173)
+                const float lx = f_of(W[P.ray_off + 3 * j]), ly = f_of(W[P.ray_off + 3 * j + 1]),
+                            lz = f_of(W[P.ray_off + 3 * j + 2]);
+                float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
+                if (P.ray_yaw_only) {
+                    quat_apply_yaw_only(s[16], s[17], lx, ly, lz, sx, sy, sz);
+                } else {
+                    quat_apply(s[12], s[13], s[14], s[15], lx, ly, lz, sx, sy, sz);
+                    quat_apply(s[12], s[13], s[14], s[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
+                }
+                sx += s[9]; sy += s[10]; sz += s[11];
+                float t;
+                int32_t face;
+                float hx, hy, hz;
+                if (cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)) {
+                    hx = sx + t * dx; hy = sy + t * dy; hz = sz + t * dz;  // kernels.py:69
+                } else {
+                    hx = hy = hz = __builtin_huge_valf();  // ops.py:70
+                }
+                if (ray_hits_out) {
+                    float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
+                    o[0] = hx; o[1] = hy; o[2] = hz;
+                }
+                v = s[11] - hz - f_of(r[IMX_R_P0]);
+            } break;
+            default: break;
+        }
+        // post-processing order: noise -> clip -> scale (observation_manager.py:313-318)
+        if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
+            const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
+            const float lo = f_of(r[IMX_R_NOISE_LO]), hi = f_of(r[IMX_R_NOISE_HI]);
+            const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
+            v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
+        }
+        if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, f_of(r[IMX_R_CLIP_LO])), f_of(r[IMX_R_CLIP_HI]));
+        if (flags & IMX_F_SCALE) v = v * f_of(r[IMX_R_SCALE]);
+        Bf.obs[e * D + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- root frame
+__global__ void k_root_frame(int64_t N, const float* __restrict__ q, const float* __restrict__ lv,
+                             const float* __restrict__ av, float gx, float gy, float gz, float* __restrict__ olv,
+                             float* __restrict__ oav, float* __restrict__ opg) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const float w = q[e * 4], x = q[e * 4 + 1], y = q[e * 4 + 2], z = q[e * 4 + 3];
+    float a, b, c;
+    if (olv) { quat_rotate_inverse(w, x, y, z, lv[e * 3], lv[e * 3 + 1], lv[e * 3 + 2], a, b, c); olv[e * 3] = a; olv[e * 3 + 1] = b; olv[e * 3 + 2] = c; }
+    if (oav) { quat_rotate_inverse(w, x, y, z, av[e * 3], av[e * 3 + 1], av[e * 3 + 2], a, b, c); oav[e * 3] = a; oav[e * 3 + 1] = b; oav[e * 3 + 2] = c; }
+    if (opg) { quat_rotate_inverse(w, x, y, z, gx, gy, gz, a, b, c); opg[e * 3] = a; opg[e * 3 + 1] = b; opg[e * 3 + 2] = c; }
+}
+
+// ------------------------------------------------------------------------------------------------- raycast_mesh
+__global__ void k_raycast(MeshView M, const float* __restrict__ starts, const float* __restrict__ dirs, int64_t n,
+                          float max_dist, float* __restrict__ hits, float* __restrict__ dist, int32_t* __restrict__ faces) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = starts[i * 3], oy = starts[i * 3 + 1], oz = starts[i * 3 + 2];
+    const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+    float t;
+    int32_t f;
+    const float inf = __builtin_huge_valf();
+    if (cast_ray(M, ox, oy, oz, dx, dy, dz, max_dist, t, f)) {
+        hits[i * 3] = ox + t * dx; hits[i * 3 + 1] = oy + t * dy; hits[i * 3 + 2] = oz + t * dz;
+        if (dist) dist[i] = t;
+        if (faces) faces[i] = f;
+    } else {
+        hits[i * 3] = inf; hits[i * 3 + 1] = inf; hits[i * 3 + 2] = inf;
+        if (dist) dist[i] = inf;
+        if (faces) faces[i] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- C ABI
+static int check_common(const imx_plan_t* plan, int64_t N, const imx_state_t* st, const imx_buffers_t* bf) {
+    IMX_REQUIRE(plan && st && bf, "null plan/state/buffers");
+    IMX_REQUIRE(plan->dev, "plan has no device copy (no GPU visible when it was created)");
+    IMX_REQUIRE(N > 0 && N < (1ll << 31), "num_envs out of range: %lld", (long long)N);
+    return 0;
+}
+
+extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float* actions_d, float pre_clip,
+                                  const imx_state_t* st, const imx_buffers_t* bf, imx_stream_t stream) {
+    if (check_common(plan, N, st, bf)) return 1;
+    IMX_REQUIRE(actions_d && bf->action && bf->prev_action && bf->processed_action, "imx_action_process: null buffer");
+    IMX_REQUIRE(plan->A > 0, "imx_action_process: plan has no action columns");
+    for (int k = 0; k < plan->nact; ++k) {
+        const int flags = plan->host[plan->act_off + k * IMX_REC_WORDS + IMX_R_FLAGS];
+        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) IMX_REQUIRE(st->default_joint_pos, "default_joint_pos missing");
+        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) IMX_REQUIRE(st->default_joint_vel, "default_joint_vel missing");
+    }
+    const int64_t n = N * plan->A;
+    const int bs = 256;
+    hipLaunchKernelGGL(k_action, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream,
+                       imx_plan_view(plan), N, actions_d, pre_clip, *st, *bf);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const imx_state_t* st,
+                                        const imx_buffers_t* bf, imx_stream_t stream) {
+    if (check_common(plan, N, st, bf)) return 1;
+    IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w, "root state missing");
+    IMX_REQUIRE(bf->episode_length_buf && bf->reward_buf && bf->episode_sums && bf->step_reward && bf->term_dones &&
+                    bf->terminated && bf->truncated && bf->reset_buf && bf->reset_env_ids && bf->counters &&
+                    bf->log_out && bf->scratch && bf->action && bf->prev_action,
+                "imx_terminations_rewards: null buffer");
+    // inputs each op dereferences must be present
+    const auto& w = plan->host;
+    auto need = [&](const void* p, const char* name) -> int {
+        IMX_REQUIRE(p, "state tensor '%s' is required by a term but missing", name);
+        return 0;
+    };
+    for (int k = 0; k < plan->nterm; ++k) {
+        switch (w[plan->term_off + k * IMX_REC_WORDS + IMX_R_OP]) {
+            case IMX_T_ILLEGAL_CONTACT: if (need(st->net_forces_w_history, "net_forces_w_history")) return 1; break;
+            case IMX_T_JOINT_POS_MANUAL_LIMIT: if (need(st->joint_pos, "joint_pos")) return 1; break;
+            case IMX_T_ROOT_HEIGHT_BELOW_MIN: case IMX_T_TERRAIN_OUT_OF_BOUNDS: if (need(st->root_pos_w, "root_pos_w")) return 1; break;
+            case IMX_T_JOINT_VEL_LIMIT: if (need(st->joint_vel, "joint_vel") || need(st->soft_joint_vel_limits, "soft_joint_vel_limits")) return 1; break;
+            case IMX_T_JOINT_VEL_MANUAL_LIMIT: if (need(st->joint_vel, "joint_vel")) return 1; break;
+            case IMX_T_JOINT_EFFORT_LIMIT: if (need(st->computed_torque, "computed_torque") || need(st->applied_torque, "applied_torque")) return 1; break;
+            case IMX_T_EXTERNAL: if (need(st->ext_term, "ext_term")) return 1; break;
+            default: break;
+        }
+    }
+    for (int k = 0; k < plan->nrew; ++k) {
+        switch (w[plan->rew_off + k * IMX_REC_WORDS + IMX_R_OP]) {
+            case IMX_W_BASE_HEIGHT_L2: if (need(st->root_pos_w, "root_pos_w")) return 1; break;
+            case IMX_W_JOINT_TORQUES_L2: if (need(st->applied_torque, "applied_torque")) return 1; break;
+            case IMX_W_JOINT_VEL_L1: case IMX_W_JOINT_VEL_L2: if (need(st->joint_vel, "joint_vel")) return 1; break;
+            case IMX_W_JOINT_ACC_L2: if (need(st->joint_acc, "joint_acc")) return 1; break;
+            case IMX_W_JOINT_DEVIATION_L1: if (need(st->joint_pos, "joint_pos") || need(st->default_joint_pos, "default_joint_pos")) return 1; break;
+            case IMX_W_JOINT_POS_LIMITS: if (need(st->joint_pos, "joint_pos") || need(st->soft_joint_pos_limits, "soft_joint_pos_limits")) return 1; break;
+            case IMX_W_JOINT_VEL_LIMITS: if (need(st->joint_vel, "joint_vel") || need(st->soft_joint_vel_limits, "soft_joint_vel_limits")) return 1; break;
+            case IMX_W_APPLIED_TORQUE_LIMITS: if (need(st->applied_torque, "applied_torque") || need(st->computed_torque, "computed_torque")) return 1; break;
+            case IMX_W_UNDESIRED_CONTACTS: case IMX_W_CONTACT_FORCES: if (need(st->net_forces_w_history, "net_forces_w_history")) return 1; break;
+            case IMX_W_TRACK_LIN_VEL_XY_EXP: case IMX_W_TRACK_ANG_VEL_Z_EXP: case IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP:
+            case IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP: if (need(st->command, "command")) return 1; break;
+            case IMX_W_FEET_AIR_TIME: if (need(st->command, "command") || need(st->current_contact_time, "current_contact_time") || need(st->last_air_time, "last_air_time")) return 1; break;
+            case IMX_W_FEET_AIR_TIME_POSITIVE_BIPED: if (need(st->command, "command") || need(st->current_contact_time, "current_contact_time") || need(st->current_air_time, "current_air_time")) return 1; break;
+            case IMX_W_FEET_SLIDE: if (need(st->net_forces_w_history, "net_forces_w_history") || need(st->body_lin_vel_w, "body_lin_vel_w")) return 1; break;
+            case IMX_W_JOINT_POS_TARGET_L2: if (need(st->joint_pos, "joint_pos")) return 1; break;
+            case IMX_W_EXTERNAL: if (need(st->ext_reward, "ext_reward")) return 1; break;
+            default: break;
+        }
+    }
+    if (plan->CMD > 0 && !st->command) IMX_FAIL("command tensor missing");
+    const int bs = (N <= 16384) ? 64 : 256;
+    const unsigned grid = (unsigned)((N + bs - 1) / bs);
+    StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
+    hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(bs), 0, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, sc);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_state_t* st, const imx_buffers_t* bf,
+                                const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
+                                float* ray_hits_out_d, imx_stream_t stream) {
+    if (check_common(plan, N, st, bf)) return 1;
+    IMX_REQUIRE(bf->obs && bf->counters, "imx_observations: null obs/counters buffer");
+    IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w && st->root_pos_w, "root state missing");
+    IMX_REQUIRE(!plan->needs_mesh || mesh, "plan has a height_scan term but no mesh was given");
+    const auto& w = plan->host;
+    for (int k = 0; k < plan->nobs; ++k) {
+        const int op = w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP];
+        const void* p = (const void*)1;
+        const char* name = "";
+        switch (op) {
+            case IMX_O_ROOT_POS_W: p = st->env_origins; name = "env_origins"; break;
+            case IMX_O_JOINT_POS: p = st->joint_pos; name = "joint_pos"; break;
+            case IMX_O_JOINT_POS_REL: p = (st->joint_pos && st->default_joint_pos) ? (const void*)1 : nullptr; name = "joint_pos/default_joint_pos"; break;
+            case IMX_O_JOINT_POS_LIMIT_NORMALIZED: p = (st->joint_pos && st->soft_joint_pos_limits) ? (const void*)1 : nullptr; name = "joint_pos/soft_joint_pos_limits"; break;
+            case IMX_O_JOINT_VEL: p = st->joint_vel; name = "joint_vel"; break;
+            case IMX_O_JOINT_VEL_REL: p = (st->joint_vel && st->default_joint_vel) ? (const void*)1 : nullptr; name = "joint_vel/default_joint_vel"; break;
+            case IMX_O_LAST_ACTION: p = bf->action; name = "action"; break;
+            case IMX_O_GENERATED_COMMANDS: p = st->command; name = "command"; break;
+            case IMX_O_EXTERNAL: p = st->ext_obs; name = "ext_obs"; break;
+            default: break;
+        }
+        IMX_REQUIRE(p, "state tensor '%s' is required by an observation term but missing", name);
+    }
+    MeshView mv{};
+    if (mesh) mv = mesh->v;
+    constexpr int EB = 8;
+    const unsigned grid = (unsigned)((N + EB - 1) / EB);
+    hipLaunchKernelGGL(k_obs<EB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, mv,
+                       noise_u_d, seed, enable_corruption, ray_hits_out_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_root_frame(int64_t N, const float* q, const float* lv, const float* av, float gx, float gy, float gz,
+                              float* olv, float* oav, float* opg, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && q, "imx_root_frame: bad arguments");
+    IMX_REQUIRE((!olv || lv) && (!oav || av), "imx_root_frame: output requested without its input");
+    hipLaunchKernelGGL(k_root_frame, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, q, lv, av,
+                       gx, gy, gz, olv, oav, opg);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_raycast(const imx_mesh_t* mesh, const float* starts, const float* dirs, int64_t n, float max_dist,
+                           float* hits, float* dist, int32_t* faces, imx_stream_t stream) {
+    IMX_REQUIRE(mesh && starts && dirs && hits, "imx_raycast: null argument");
+    if (n == 0) return 0;
+    IMX_REQUIRE(n > 0, "imx_raycast: negative ray count");
+    hipLaunchKernelGGL(k_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mesh->v, starts,
+                       dirs, n, max_dist, hits, dist, faces);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

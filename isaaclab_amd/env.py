@@ -1,0 +1,620 @@
+"""``ManagerBasedRLEnv`` on libimx: the reference's gym surface (isaaclab/envs/manager_based_rl_env.py:26-392,
+isaaclab/envs/manager_based_env.py:264-315) with the post-physics step executed by three HIP kernels.
+
+    step(action):  imx_action_process -> [physics = StateFeed.advance()] -> imx_terminations_rewards
+                   -> imx_observations            (no host synchronisation anywhere on the path)
+
+PhysX / InteractiveScene / Event- / Curriculum- / CommandManager are out of scope: their
+outputs arrive as tensors from a :class:`~isaaclab_amd.state_feed.StateFeed`.  The manager objects below keep the
+reference's public attribute names so that user code (`env.reward_manager._episode_sums[...]`,
+`env.termination_manager.time_outs`, `env.action_manager.action` ...) keeps working; they are views over the
+buffers the kernels write.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import importlib
+import json
+import math
+import os
+from collections.abc import Sequence
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ImxBuffers, ImxState, check, lib
+from .plan import Plan, compile_plan
+from .robots import ROBOTS, RobotSpec
+from .state_feed import StateFeed
+
+_CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+
+def load_task_cfg(task: str) -> dict:
+    """Config fixture captured from the reference's gym registry entry ``task`` (``cfg.to_dict()`` form)."""
+    path = os.path.join(_CFG_DIR, task + ".json")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"no config fixture for task '{task}' under {_CFG_DIR}")
+    with open(path) as f:
+        return json.load(f)
+
+
+def _string_to_callable(name: str):
+    """isaaclab/utils/string.py:138-176"""
+    mod, _, attr = name.partition(":")
+    obj = importlib.import_module(mod)
+    for part in attr.split("."):
+        obj = getattr(obj, part)
+    if not callable(obj):
+        raise AttributeError(f"The imported object is not callable: '{name}'")
+    return obj
+
+
+class TerrainMesh:
+    """Device mesh + grid for the ray-caster (``imx_mesh_create``)."""
+
+    def __init__(self, vertices: np.ndarray, triangles: np.ndarray, cell_size: float = 0.0):
+        v = np.ascontiguousarray(vertices, np.float32)
+        t = np.ascontiguousarray(triangles, np.uint32)
+        if v.ndim != 2 or v.shape[1] != 3 or t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("vertices must be (V,3) float and triangles (F,3) integer arrays")
+        self._h = ctypes.c_void_p()
+        check(lib().imx_mesh_create(v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0], float(cell_size),
+                                    ctypes.byref(self._h)))
+        info = (ctypes.c_int64 * 8)()
+        check(lib().imx_mesh_info(self._h, info))
+        self.nx, self.ny, self.num_triangles, self.num_refs, self.max_refs = (int(info[i]) for i in range(5))
+        self.num_vertices = v.shape[0]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def raycast(self, ray_starts: torch.Tensor, ray_directions: torch.Tensor, max_dist: float = 1e6,
+                return_distance: bool = False, return_face_id: bool = False):
+        """``raycast_mesh`` (isaaclab/utils/warp/ops.py:24-127): hits (+inf on miss) [, distance, face id]."""
+        shape = ray_starts.shape
+        s = ray_starts.reshape(-1, 3).contiguous().float()
+        d = ray_directions.reshape(-1, 3).contiguous().float()
+        n = s.shape[0]
+        hits = torch.empty_like(s)
+        dist = torch.empty(n, device=s.device) if return_distance else None
+        face = torch.empty(n, dtype=torch.int32, device=s.device) if return_face_id else None
+        check(lib().imx_raycast(self._h, s.data_ptr(), d.data_ptr(), n, float(max_dist), hits.data_ptr(),
+                                _lib.ptr(dist), _lib.ptr(face), _lib.current_stream(s.device)))
+        return (hits.view(shape), None if dist is None else dist.view(shape[:-1]), None,
+                None if face is None else face.view(shape[:-1]))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().imx_mesh_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------- manager views
+class _ActionTermView:
+    def __init__(self, env, name, col0, dim):
+        self._env, self.name, self._c0, self.action_dim = env, name, col0, dim
+
+    @property
+    def raw_actions(self):
+        return self._env._action[:, self._c0:self._c0 + self.action_dim]
+
+    @property
+    def processed_actions(self):
+        return self._env._processed_action[:, self._c0:self._c0 + self.action_dim]
+
+
+class ActionManager:
+    """View with the public surface of isaaclab/managers/action_manager.py:228-359."""
+
+    def __init__(self, env: "ManagerBasedRLEnv"):
+        self._env = env
+        self._terms = {}
+        c = 0
+        for t in env.plan.action_terms:
+            self._terms[t.name] = _ActionTermView(env, t.name, c, t.dim)
+            c += t.dim
+
+    @property
+    def active_terms(self) -> list[str]:
+        return list(self._terms)
+
+    @property
+    def total_action_dim(self) -> int:
+        return self._env.plan.action_dim
+
+    @property
+    def action_term_dim(self) -> list[int]:
+        return [t.action_dim for t in self._terms.values()]
+
+    @property
+    def action(self) -> torch.Tensor:
+        return self._env._action
+
+    @property
+    def prev_action(self) -> torch.Tensor:
+        return self._env._prev_action
+
+    def get_term(self, name: str):
+        return self._terms[name]
+
+    def process_action(self, action: torch.Tensor):
+        self._env._process_action(action)
+
+    def apply_action(self):  # the processed targets would go to PhysX here
+        pass
+
+    def reset(self, env_ids=None) -> dict:
+        ids = slice(None) if env_ids is None else env_ids
+        self._env._prev_action[ids] = 0.0
+        self._env._action[ids] = 0.0
+        return {}
+
+
+class ObservationManager:
+    """isaaclab/managers/observation_manager.py:177-335 surface for the fused 'policy' group."""
+
+    def __init__(self, env: "ManagerBasedRLEnv", group: str = "policy"):
+        self._env, self._group = env, group
+
+    @property
+    def active_terms(self):
+        return {self._group: [t.name for t in self._env.plan.obs_terms]}
+
+    @property
+    def group_obs_dim(self):
+        return {self._group: (self._env.plan.obs_dim,)}
+
+    @property
+    def group_obs_term_dim(self):
+        return {self._group: list(self._env.plan.obs_term_dims)}
+
+    @property
+    def group_obs_concatenate(self):
+        return {self._group: True}
+
+    def compute(self) -> dict:
+        return {self._group: self.compute_group(self._group)}
+
+    def compute_group(self, group_name: str):
+        if group_name != self._group:
+            raise ValueError(f"Unable to find the group '{group_name}' in the observation manager."
+                             f" Available groups are: {[self._group]}")
+        return self._env._compute_observations()
+
+    def reset(self, env_ids=None) -> dict:
+        return {}
+
+
+class RewardManager:
+    """isaaclab/managers/reward_manager.py:91-209 surface; buffers are written by imx_terminations_rewards."""
+
+    def __init__(self, env: "ManagerBasedRLEnv"):
+        self._env = env
+        self._term_names = [t.name for t in env.plan.reward_terms]
+        self._episode_sums = {n: env._episode_sums[i] for i, n in enumerate(self._term_names)}
+        self._step_reward = env._step_reward
+        self._reward_buf = env._reward_buf
+
+    @property
+    def active_terms(self) -> list[str]:
+        return self._term_names
+
+    def compute(self, dt: float | None = None) -> torch.Tensor:
+        """The reward is produced together with the terminations by ``env.step``; this returns that buffer."""
+        return self._reward_buf
+
+    def get_term_cfg(self, term_name: str):
+        if term_name not in self._term_names:
+            raise ValueError(f"Reward term '{term_name}' not found.")
+        return self._env.plan.reward_terms[self._term_names.index(term_name)]
+
+    def reset(self, env_ids=None) -> dict:
+        """Episode_Reward/<term> = mean(episode_sum[ids]) / max_episode_length_s, then zero (reward_manager.py:100-126)."""
+        ids = slice(None) if env_ids is None else env_ids
+        extras = {}
+        for i, key in enumerate(self._term_names):
+            extras["Episode_Reward/" + key] = torch.mean(self._env._episode_sums[i][ids]) / self._env.max_episode_length_s
+            self._env._episode_sums[i][ids] = 0.0
+        return extras
+
+    def get_active_iterable_terms(self, env_idx: int):
+        return [(n, [self._step_reward[env_idx, i].cpu().item()]) for i, n in enumerate(self._term_names)]
+
+
+class TerminationManager:
+    """isaaclab/managers/termination_manager.py:94-185 surface."""
+
+    def __init__(self, env: "ManagerBasedRLEnv"):
+        self._env = env
+        self._term_names = [t.name for t in env.plan.termination_terms]
+        self._term_dones = {n: env._term_dones[i] for i, n in enumerate(self._term_names)}
+
+    @property
+    def active_terms(self) -> list[str]:
+        return self._term_names
+
+    @property
+    def dones(self) -> torch.Tensor:
+        return self._env.reset_buf
+
+    @property
+    def time_outs(self) -> torch.Tensor:
+        return self._env.reset_time_outs
+
+    @property
+    def terminated(self) -> torch.Tensor:
+        return self._env.reset_terminated
+
+    def compute(self) -> torch.Tensor:
+        return self._env.reset_buf
+
+    def get_term(self, name: str) -> torch.Tensor:
+        return self._term_dones[name]
+
+    def find_terms(self, name_keys):
+        from .robots import resolve_matching_names
+
+        return resolve_matching_names(name_keys, self._term_names)[1]
+
+    def reset(self, env_ids=None) -> dict:
+        ids = slice(None) if env_ids is None else env_ids
+        return {"Episode_Termination/" + k: torch.count_nonzero(v[ids]).item() for k, v in self._term_dones.items()}
+
+
+class CommandManager:
+    """Commands come from the feed (UniformVelocityCommand is a SURVEY 8f 'next' row)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def get_command(self, name: str) -> torch.Tensor:
+        return self._env.feed["command"]
+
+    def compute(self, dt: float):
+        pass
+
+    def reset(self, env_ids=None) -> dict:
+        return {}
+
+
+class _FeedData:
+    """``asset.data`` / ``sensor.data`` for Python fallback terms: feed tensors + libimx-derived root-frame vectors."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getattr__(self, name):
+        env = self.__dict__["_env"]
+        if name in ("root_lin_vel_b", "root_ang_vel_b", "projected_gravity_b"):
+            return env._root_frame()[name]
+        if name == "root_link_quat_w":
+            name = "root_quat_w"
+        try:
+            return env.feed[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+
+class _Entity:
+    def __init__(self, env, names_joint, names_body):
+        self.data = _FeedData(env)
+        self.joint_names, self.body_names = list(names_joint), list(names_body)
+        self.num_joints, self.num_bodies = len(names_joint), len(names_body)
+
+    def find_joints(self, keys, joint_subset=None, preserve_order=False):
+        from .robots import resolve_matching_names
+
+        return resolve_matching_names(keys, self.joint_names, preserve_order)
+
+    def find_bodies(self, keys, preserve_order=False):
+        from .robots import resolve_matching_names
+
+        return resolve_matching_names(keys, self.body_names, preserve_order)
+
+
+class _Scene:
+    def __init__(self, env):
+        r = env.plan.robot
+        self._e = {"robot": _Entity(env, r.joint_names, r.body_names)}
+        self.sensors = {"contact_forces": _Entity(env, [], r.body_names)}
+        self._e.update(self.sensors)
+        self._env = env
+        self.num_envs = env.num_envs
+
+    @property
+    def env_origins(self):
+        return self._env.feed["env_origins"]
+
+    def keys(self):
+        return list(self._e)
+
+    def __getitem__(self, k):
+        return self._e[k]
+
+
+# ---------------------------------------------------------------------------------------------------- the env
+class ManagerBasedRLEnv:
+    """Drop-in for ``isaaclab.envs.ManagerBasedRLEnv`` on the fused HIP path.
+
+    Args:
+        cfg: a reference ``ManagerBasedRLEnvCfg`` instance, its ``to_dict()`` form, a fixture dict from
+            :func:`load_task_cfg`, or a task id string (e.g. ``"Isaac-Velocity-Rough-Anymal-C-v0"``).
+        render_mode: kept for signature compatibility (rendering is out of scope).
+        state_feed: the :class:`StateFeed` standing in for PhysX; synthetic one is generated when omitted.
+        terrain: ``(vertices, triangles)`` or :class:`TerrainMesh` for configs with a height scanner.
+    """
+
+    metadata = {"render_modes": [None]}
+    is_vector_env = True
+
+    def __init__(self, cfg: Any, render_mode: str | None = None, *, state_feed: StateFeed | None = None,
+                 robot: RobotSpec | str | None = None, terrain=None, num_envs: int | None = None,
+                 device: str | torch.device | None = None, seed: int | None = None, noise_seed: int = 0,
+                 terrain_cell: float = 0.0, **kwargs):
+        if isinstance(cfg, str):
+            cfg = load_task_cfg(cfg)
+        self.cfg = cfg
+        env_cfg = cfg
+        robot_name = robot
+        if isinstance(cfg, dict) and "env" in cfg and "task" in cfg:  # fixture wrapper
+            env_cfg = cfg["env"]
+            robot_name = robot_name or cfg.get("robot")
+            self.agent_cfg = cfg.get("agent")
+        if isinstance(robot_name, str):
+            robot_name = ROBOTS[robot_name]
+        if robot_name is None:
+            if state_feed is None:
+                raise ValueError("pass robot= (RobotSpec or name) or a state_feed when cfg is not a task fixture")
+            robot_name = state_feed.robot
+        self.render_mode = render_mode
+        self.plan: Plan = compile_plan(env_cfg, robot_name)
+        plan = self.plan
+        env_dict = env_cfg if isinstance(env_cfg, dict) else env_cfg.to_dict()
+        if device is None:
+            device = state_feed.device if state_feed is not None else ("cuda:0" if torch.cuda.is_available() else None)
+        if device is None or torch.device(device).type != "cuda":
+            raise _lib.ImxError("ManagerBasedRLEnv runs on an MI355X through libimx; no GPU device is available "
+                                f"(device={device}). There is no CPU fallback.")
+        self.device = torch.device(device)
+        self._lib = lib()
+        N = num_envs or (state_feed.num_envs if state_feed is not None else int(env_dict["scene"]["num_envs"]))
+        self.num_envs = N
+        extent = None
+        self.terrain: TerrainMesh | None = None
+        if plan.num_rays > 0:
+            if terrain is None:
+                raise ValueError("this config has a height scanner: pass terrain=(vertices, triangles)")
+            if isinstance(terrain, TerrainMesh):
+                self.terrain = terrain
+            else:
+                verts, tris = terrain[0], terrain[1]
+                self.terrain = TerrainMesh(verts, tris, terrain_cell)
+                v = np.asarray(verts)
+                extent = (float(np.abs(v[:, 0]).max()) - 2.0, float(np.abs(v[:, 1]).max()) - 2.0)
+        if state_feed is None:
+            state_feed = StateFeed(plan.robot, N, self.device, seed=42 if seed is None else seed, extent_xy=extent,
+                                   history=plan.history, gravity=tuple(env_dict["sim"].get("gravity", (0, 0, -9.81))))
+        if state_feed.num_envs != N or torch.device(state_feed.device) != self.device:
+            raise ValueError("state_feed has a different num_envs/device than the env")
+        self.feed = state_feed
+        self.step_dt = plan.step_dt
+        self.physics_dt = float(env_dict["sim"]["dt"])
+        self.max_episode_length = plan.max_episode_length
+        self.max_episode_length_s = plan.max_episode_length_s
+        self.common_step_counter = 0
+        self._sim_step_counter = 0
+        self.noise_seed = int(noise_seed)
+        self.clip_actions: float | None = None  # set by RslRlVecEnvWrapper: fused into imx_action_process
+        self.extras: dict = {}
+
+        # ---- persistent buffers (manager state); pointers stay fixed so steps can be captured in a hipGraph
+        dev, K, NT = self.device, max(len(plan.reward_terms), 1), max(len(plan.termination_terms), 1)
+        A, D = plan.action_dim, plan.obs_dim
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        self._episode_length_buf = z(N, dtype=torch.long)
+        self._action, self._prev_action, self._processed_action = z(N, max(A, 1)), z(N, max(A, 1)), z(N, max(A, 1))
+        self._reward_buf = z(N)
+        self._episode_sums = z(K, N)
+        self._step_reward = z(N, K)
+        self._term_dones = z(NT, N, dtype=torch.bool)
+        self.reset_terminated, self.reset_time_outs, self.reset_buf = (z(N, dtype=torch.bool) for _ in range(3))
+        self._reset_env_ids = z(N, dtype=torch.long)
+        self._counters = z(8, dtype=torch.int32)
+        self._log_out = z(K + NT + 1)
+        self._obs = z(N, max(D, 1))
+        self._ext_reward = z(N, plan.n_ext_rew) if plan.n_ext_rew else None
+        self._ext_term = z(N, plan.n_ext_term, dtype=torch.bool) if plan.n_ext_term else None
+        self._ext_obs = z(N, plan.n_ext_obs) if plan.n_ext_obs else None
+        self._noise_u: torch.Tensor | None = None  # parity mode: uniforms replacing torch.rand_like
+        self.materialize_ray_hits = False
+        self._ray_hits = None
+        self.reward_buf = self._reward_buf
+        self.obs_buf = {"policy": self._obs}
+
+        blob = np.ascontiguousarray(plan.blob, np.int32)
+        self._plan_h = ctypes.c_void_p()
+        check(self._lib.imx_plan_create(blob.ctypes.data, blob.size, ctypes.byref(self._plan_h)))
+        self._scratch = torch.zeros(int(self._lib.imx_plan_scratch_bytes(self._plan_h, N)), dtype=torch.uint8, device=dev)
+        self._bufs = ImxBuffers(
+            episode_length_buf=self._episode_length_buf.data_ptr(), action=self._action.data_ptr(),
+            prev_action=self._prev_action.data_ptr(), processed_action=self._processed_action.data_ptr(),
+            reward_buf=self._reward_buf.data_ptr(), episode_sums=self._episode_sums.data_ptr(),
+            step_reward=self._step_reward.data_ptr(), term_dones=self._term_dones.data_ptr(),
+            terminated=self.reset_terminated.data_ptr(), truncated=self.reset_time_outs.data_ptr(),
+            reset_buf=self.reset_buf.data_ptr(), reset_env_ids=self._reset_env_ids.data_ptr(),
+            counters=self._counters.data_ptr(), log_out=self._log_out.data_ptr(), obs=self._obs.data_ptr(),
+            scratch=self._scratch.data_ptr())
+        self._state_cache: dict[int, ImxState] = {}
+        self._root_cache = None
+
+        self.action_manager = ActionManager(self)
+        self.observation_manager = ObservationManager(self)
+        self.reward_manager = RewardManager(self)
+        self.termination_manager = TerminationManager(self)
+        self.command_manager = CommandManager(self)
+        self.scene = _Scene(self)
+        self._ext_funcs = {
+            "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None and t.weight != 0.0],
+            "term": [(t, self._resolve_ext(t)) for t in plan.termination_terms if t.external is not None],
+            "obs": [(t, self._resolve_ext(t)) for t in plan.obs_terms if t.external is not None],
+        }
+        names_r = [t.name for t in plan.reward_terms]
+        names_t = [t.name for t in plan.termination_terms]
+        self._log_views = {"Episode_Reward/" + n: self._log_out[i] for i, n in enumerate(names_r)}
+        self._log_views.update({"Episode_Termination/" + n: self._log_out[len(names_r) + i] for i, n in enumerate(names_t)})
+        if seed is not None:
+            self.seed(seed)
+
+    # ---- gym-ish properties ------------------------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def episode_length_buf(self) -> torch.Tensor:
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value: torch.Tensor):
+        # RSL-RL's init_at_random_ep_len assigns a new tensor (vecenv_wrapper.py:144-156); keep the pointer stable
+        self._episode_length_buf.copy_(value.to(self.device, torch.long))
+
+    @property
+    def reset_env_ids(self) -> torch.Tensor:
+        """Ascending ids of the envs reset in the last step (host sync: reads the device-side count)."""
+        return self._reset_env_ids[: int(self._counters[0].item())]
+
+    @staticmethod
+    def seed(seed: int = -1) -> int:
+        torch.manual_seed(seed)
+        np.random.seed(seed % (2 ** 32))
+        return seed
+
+    def close(self):
+        if getattr(self, "_plan_h", None):
+            self._lib.imx_plan_destroy(self._plan_h)
+            self._plan_h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- internals -------------------------------------------------------------------------------------------------
+    def _resolve_ext(self, term):
+        f = term.external
+        return _string_to_callable(f) if isinstance(f, str) else f
+
+    def _state(self) -> ImxState:
+        idx = self.feed.index
+        st = self._state_cache.get(idx)
+        if st is None:
+            snap = self.feed.snapshot(idx)
+            kw = {n: snap[n].data_ptr() for n in _lib.STATE_FIELDS if n in snap}
+            kw["ext_reward"] = _lib.ptr(self._ext_reward)
+            kw["ext_term"] = _lib.ptr(self._ext_term)
+            kw["ext_obs"] = _lib.ptr(self._ext_obs)
+            st = ImxState(**kw)
+            self._state_cache[idx] = st
+        return st
+
+    def _root_frame(self) -> dict:
+        N, f = self.num_envs, self.feed
+        out = {k: torch.empty(N, 3, device=self.device) for k in ("root_lin_vel_b", "root_ang_vel_b", "projected_gravity_b")}
+        g = self.plan.gravity_dir
+        check(self._lib.imx_root_frame(N, f["root_quat_w"].data_ptr(), f["root_lin_vel_w"].data_ptr(),
+                                       f["root_ang_vel_w"].data_ptr(), g[0], g[1], g[2], out["root_lin_vel_b"].data_ptr(),
+                                       out["root_ang_vel_b"].data_ptr(), out["projected_gravity_b"].data_ptr(),
+                                       _lib.current_stream(self.device)))
+        return out
+
+    def _process_action(self, action: torch.Tensor):
+        A = self.plan.action_dim
+        if action.shape[1] != A:  # action_manager.py:328-329
+            raise ValueError(f"Invalid action shape, expected: {A}, received: {action.shape[1]}.")
+        a = action.to(self.device, torch.float32).contiguous()
+        clip = math.inf if self.clip_actions is None else float(self.clip_actions)
+        check(self._lib.imx_action_process(self._plan_h, self.num_envs, a.data_ptr(), clip, ctypes.byref(self._state()),
+                                           ctypes.byref(self._bufs), _lib.current_stream(self.device)))
+
+    def _eval_external(self, kind: str):
+        for col, (term, fn) in enumerate(self._ext_funcs[kind]):
+            val = fn(self, **term.params)
+            if kind == "rew":
+                self._ext_reward[:, col] = val
+            elif kind == "term":
+                self._ext_term[:, col] = val
+        if kind == "obs":
+            c = 0
+            for term, fn in self._ext_funcs["obs"]:
+                self._ext_obs[:, c:c + term.dim] = fn(self, **term.params).reshape(self.num_envs, -1)
+                c += term.dim
+
+    def _compute_observations(self) -> torch.Tensor:
+        if self._ext_funcs["obs"]:
+            self._eval_external("obs")
+        hits = None
+        if self.materialize_ray_hits and self.plan.num_rays:
+            if self._ray_hits is None:
+                self._ray_hits = torch.empty(self.num_envs, self.plan.num_rays, 3, device=self.device)
+            hits = self._ray_hits.data_ptr()
+        check(self._lib.imx_observations(
+            self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
+            self.terrain.handle if self.terrain is not None else None, _lib.ptr(self._noise_u), self.noise_seed,
+            1 if self.plan.enable_corruption else 0, hits, _lib.current_stream(self.device)))
+        return self._obs
+
+    # ---- MDP operations ------------------------------------------------------------------------------------------
+    def reset(self, seed: int | None = None, env_ids: Sequence[int] | None = None, options: dict | None = None):
+        """ManagerBasedEnv.reset (manager_based_env.py:264-315): reset every env, return (obs_dict, extras)."""
+        if seed is not None:
+            self.seed(seed)
+        ids = slice(None) if env_ids is None else env_ids
+        log = {}
+        log.update(self.reward_manager.reset(ids))
+        self.action_manager.reset(ids)
+        self._episode_length_buf[ids] = 0
+        self.extras["log"] = log
+        obs = self._compute_observations()
+        return {"policy": obs}, self.extras
+
+    def step(self, action: torch.Tensor):
+        """ManagerBasedRLEnv.step (manager_based_rl_env.py:153-242)."""
+        # -- pre-physics
+        self._process_action(action)
+        # -- physics (decimation x sim.step) is replaced by the feed moving to its next recorded state
+        self._sim_step_counter += int(self.cfg_decimation)
+        self.feed.advance()
+        self.common_step_counter += 1
+        # -- post-physics: counters, terminations, rewards, reset bookkeeping (one kernel)
+        if self._ext_funcs["rew"] or self._ext_funcs["term"]:
+            self._eval_external("term")
+            self._eval_external("rew")
+        check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
+                                                 ctypes.byref(self._bufs), _lib.current_stream(self.device)))
+        self.extras["log"] = self._log_views
+        # -- commands / interval events: supplied by the feed
+        # -- observations on the post-reset state (one kernel, ray-cast fused)
+        obs = self._compute_observations()
+        return {"policy": obs}, self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    @property
+    def cfg_decimation(self) -> int:
+        c = self.cfg
+        if isinstance(c, dict):
+            c = c.get("env", c)
+            return int(c.get("decimation", 1))
+        return int(getattr(c, "decimation", 1))
+
+    @property
+    def is_finite_horizon(self) -> bool:
+        return self.plan.is_finite_horizon

@@ -1,0 +1,65 @@
+"""Shared helpers: rebuild the recorded state feed / oracle from a golden fixture."""
+
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from isaaclab_amd.env import load_task_cfg
+from isaaclab_amd.robots import ROBOTS
+from isaaclab_amd.state_feed import DYNAMIC, STATIC, StateFeed
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TASKS = ("Isaac-Cartpole-v0", "Isaac-Velocity-Flat-Anymal-C-v0", "Isaac-Velocity-Rough-Anymal-C-v0",
+         "Isaac-Velocity-Rough-G1-v0")
+FLOAT_TOL = 1e-5  # BASELINE.json north_star: within 1e-5 fp32 on observations, rewards and returns
+
+
+class Golden:
+    def __init__(self, task: str):
+        self.task = task
+        self.z = np.load(os.path.join(GOLDEN, task + ".npz"))
+        self.meta = json.loads(str(self.z["meta_json"]))
+        self.fixture = load_task_cfg(task)
+        self.robot = ROBOTS[self.fixture["robot"]]
+        self.steps = self.meta["steps"]
+        self.N = self.meta["num_envs"]
+
+    def t(self, key) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(self.z[key]))
+
+    def snapshots(self):
+        """snapshot 0 = state at reset(), snapshot k+1 = state after physics of step k"""
+        out = []
+        for tag in ["reset"] + [f"step{k}" for k in range(self.steps)]:
+            d = {n: self.t(f"{tag}/in/{n}") for n in DYNAMIC}
+            d.update({n: self.t(f"static/{n}") for n in STATIC})
+            out.append(d)
+        return out
+
+    def feed(self, device="cpu") -> StateFeed:
+        return StateFeed.from_tensors(self.robot, self.snapshots(), device=device, gravity_dir=self.meta["gravity_dir"])
+
+    def mesh(self):
+        if "mesh/vertices" not in self.z:
+            return None
+        return self.z["mesh/vertices"], self.z["mesh/triangles"]
+
+    def log(self, step: int) -> dict:
+        return json.loads(str(self.z[f"step{step}/log_json"]))
+
+
+def assert_close(a, b, tol=FLOAT_TOL, what=""):
+    a = torch.as_tensor(a).float().cpu()
+    b = torch.as_tensor(b).float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin), f"{what}: finite masks differ"
+    # 1e-5 relative-or-absolute (north_star tolerance)
+    err = (a[fin] - b[fin]).abs()
+    lim = tol * torch.clamp(b[fin].abs(), min=1.0)
+    bad = err > lim
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e} (tol {tol}), {int(bad.sum())} elements over"

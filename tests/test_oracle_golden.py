@@ -1,0 +1,69 @@
+"""CPU: the oracle (oracle/mdp_oracle.py) against fixtures produced by the REAL reference managers/terms
+(oracle/gen_golden.py).  This is what pins the oracle; masks/ids bit-exact, floats <= 1e-6."""
+
+import numpy as np
+import pytest
+import torch
+
+from _util import TASKS, Golden, assert_close
+from oracle.mdp_oracle import OracleEnv
+
+
+def make_oracle(g: Golden, feed):
+    return OracleEnv(g.fixture["env"], g.robot.joint_names, g.robot.body_names, g.N, feed.__getitem__,
+                     gravity_dir=g.meta["gravity_dir"])
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_oracle_matches_reference(task):
+    g = Golden(task)
+    feed = g.feed()
+    env = make_oracle(g, feed)
+    has_scan = g.mesh() is not None
+    if has_scan:
+        env.ray_hits_w = g.t("reset/ray_hits_w")
+    obs = env.compute_observations(g.t("reset/noise_u"))
+    assert_close(obs, g.t("reset/obs"), 1e-6, "reset obs")
+    env.episode_length_buf[:] = g.t("reset/episode_length_buf")
+    for k in range(g.steps):
+        tag = f"step{k}"
+        env.process_action(g.t(f"{tag}/action"))
+        assert_close(env.processed_actions, g.t(f"{tag}/processed_actions"), 1e-6, "processed_actions")
+        feed.advance()
+        if has_scan:
+            env.ray_hits_w = g.t(f"{tag}/ray_hits_w")
+        out = env.post_physics_step(g.t(f"{tag}/noise_u"))
+        assert torch.equal(out["reset_buf"], g.t(f"{tag}/reset_buf"))
+        assert torch.equal(out["terminated"], g.t(f"{tag}/terminated"))
+        assert torch.equal(out["time_outs"], g.t(f"{tag}/time_outs"))
+        assert torch.equal(out["reset_env_ids"], g.t(f"{tag}/reset_env_ids"))
+        for name in g.meta["termination_terms"]:
+            assert torch.equal(env.term_dones[name], g.t(f"{tag}/term_dones/{name}"))
+        assert_close(out["reward"], g.t(f"{tag}/reward"), 1e-6, "reward")
+        assert_close(out["step_reward"], g.t(f"{tag}/step_reward"), 1e-6, "step_reward")
+        for name in g.meta["reward_terms"]:
+            assert_close(env.episode_sums[name], g.t(f"{tag}/episode_sums/{name}"), 1e-6, f"episode_sums/{name}")
+        assert torch.equal(env.episode_length_buf, g.t(f"{tag}/episode_length_buf"))
+        assert_close(env.action, g.t(f"{tag}/action_after_reset"), 0, "action after reset")
+        assert_close(out["obs"], g.t(f"{tag}/obs"), 1e-6, "obs")
+        ref_log = g.log(k)
+        for key, v in ref_log.items():
+            assert abs(out["log"][key] - v) <= 1e-6 * max(1.0, abs(v)), key
+
+
+def test_math_helpers_match_reference():
+    import os
+
+    from _util import GOLDEN
+    import oracle.mdp_oracle as m
+
+    z = np.load(os.path.join(GOLDEN, "math.npz"))
+    q, v, ang = (torch.from_numpy(z[k]) for k in ("q", "v", "ang"))
+    for name, got in {
+        "quat_rotate_inverse": m.quat_rotate_inverse(q, v), "quat_rotate": m.quat_rotate(q, v),
+        "quat_apply": m.quat_apply(q, v), "yaw_quat": m.yaw_quat(q), "quat_apply_yaw": m.quat_apply_yaw(q, v),
+        "wrap_to_pi": m.wrap_to_pi(ang), "normalize": m.normalize(v),
+        "convert_quat_to_wxyz": m.convert_quat(q, "wxyz"), "convert_quat_to_xyzw": m.convert_quat(q, "xyzw"),
+        "scale_transform": m.scale_transform(v, torch.from_numpy(z["lower"]), torch.from_numpy(z["upper"])),
+    }.items():
+        assert torch.equal(got, torch.from_numpy(z[name])), name  # same ops, same machine: bit-exact

@@ -1,0 +1,88 @@
+"""CPU: host logic -- name resolution, grid pattern, height-field mesh (pinned by reference fixtures), term compiler."""
+
+import os
+
+import numpy as np
+import pytest
+
+from _util import GOLDEN, TASKS, Golden
+from isaaclab_amd import plan as planmod
+from isaaclab_amd.robots import ANYMAL_C, G1, resolve_matching_names
+from isaaclab_amd.terrain import height_field_to_mesh, make_rough_terrain
+
+
+def test_resolve_matching_names_semantics():
+    # examples from the reference docstring (isaaclab/utils/string.py:178-271)
+    names = ["a", "b", "c", "d", "e"]
+    assert resolve_matching_names(["a|c", "b"], names) == ([0, 1, 2], ["a", "b", "c"])
+    assert resolve_matching_names(["a|c", "b"], names, preserve_order=True) == ([0, 2, 1], ["a", "c", "b"])
+    with pytest.raises(ValueError):
+        resolve_matching_names(["a", "a|b"], names)  # multiple matches
+    with pytest.raises(ValueError):
+        resolve_matching_names(["zzz"], names)  # unmatched key
+    assert resolve_matching_names(".*FOOT", ANYMAL_C.body_names)[0] == [13, 14, 15, 16]
+    assert len(G1.joint_names) == 37 and len(set(G1.joint_names)) == 37
+
+
+def test_grid_pattern_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "hf_mesh.npz"))
+    s, d = planmod.grid_pattern(0.1, [1.6, 1.0], (0.0, 0.0, -1.0), "xy")
+    assert s.shape == (187, 3)
+    # torch.arange(float32) evaluates vector lanes as fp32(base) + k*fp32(step): values depend on the SIMD width of
+    # the machine that ran the reference and differ from the correctly rounded start + i*step by <= 1 ulp (1.5e-8 m)
+    assert np.abs(s - z["grid_xy_starts"]).max() <= 3e-8 and np.array_equal(d, z["grid_xy_dirs"])
+    s, d = planmod.grid_pattern(0.25, [1.0, 0.5], (0.0, 0.0, -1.0), "yx")
+    assert np.abs(s - z["grid_yx_starts"]).max() <= 3e-8 and np.array_equal(d, z["grid_yx_dirs"])
+    with pytest.raises(ValueError):
+        planmod.grid_pattern(0.1, [1, 1], ordering="zz")
+    with pytest.raises(ValueError):
+        planmod.grid_pattern(0.0, [1, 1])
+
+
+def test_height_field_mesh_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "hf_mesh.npz"))
+    for thr, key in ((None, "none"), (0.75, "thr")):
+        v, t = height_field_to_mesh(z["hf"], 0.1, 0.005, thr)
+        assert np.array_equal(v, z[f"v_{key}"])
+        assert np.array_equal(t.astype(np.int64), z[f"t_{key}"])
+
+
+def test_rough_terrain_is_seeded_and_sized():
+    v1, t1, ext = make_rough_terrain(2, 2, tile=4.0, border=2.0, seed=5)
+    v2, t2, _ = make_rough_terrain(2, 2, tile=4.0, border=2.0, seed=5)
+    assert np.array_equal(v1, v2) and np.array_equal(t1, t2)
+    assert ext == (4.0, 4.0) and t1.shape[0] == 2 * 80 * 80 + 8 and t1.max() < len(v1)
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_term_compiler_matches_reference_term_tables(task):
+    g = Golden(task)
+    p = planmod.compile_plan(g.fixture["env"], g.robot)
+    assert [t.name for t in p.reward_terms] == g.meta["reward_terms"]
+    assert [t.name for t in p.termination_terms] == g.meta["termination_terms"]
+    assert [t.name for t in p.obs_terms] == g.meta["obs_terms"]
+    assert [list(d) for d in p.obs_term_dims] == g.meta["obs_term_dims"]
+    assert p.obs_dim == g.meta["obs_dim"] and p.action_dim == g.meta["action_dim"]
+    assert p.max_episode_length == g.meta["max_episode_length"]
+    assert abs(p.step_dt - g.meta["step_dt"]) < 1e-12
+    assert p.n_ext_rew == p.n_ext_term == p.n_ext_obs == 0  # everything in the target configs is fused
+
+
+def test_term_compiler_errors_follow_the_reference():
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    import copy
+
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["rewards"]["undesired_contacts"]["params"]["sensor_cfg"]["body_names"] = ".*ELBOW"
+    with pytest.raises(ValueError):
+        planmod.compile_plan(cfg, g.robot)  # regex matches nothing
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["rewards"]["lin_vel_z_l2"]["weight"] = "heavy"
+    with pytest.raises(TypeError):
+        planmod.compile_plan(cfg, g.robot)  # reward_manager.py:231-236
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["rewards"]["custom"] = {"func": "my_pkg.mdp:my_reward", "params": {}, "weight": 1.0}
+    p = planmod.compile_plan(cfg, g.robot)
+    assert p.n_ext_rew == 1 and p.reward_terms[-1].external == "my_pkg.mdp:my_reward"
+    # zero-weight terms keep their slot but emit no record (reward_manager.py:145)
+    assert p.blob[planmod.H["NREW"]] == len([t for t in p.reward_terms if t.weight != 0.0])
