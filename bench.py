@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the RSL-RL PPO loop on Isaac-Velocity-Rough-Anymal-C-v0, 4096 envs per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one PPO iteration on every rank: 24 x (actor-critic act -> imx_action_process -> [state feed advances]
+-> imx_terminations_rewards -> imx_observations(+ray-cast) -> storage) + imx_gae + 5 epochs x 4 minibatches of
+(MLP fwd -> imx_ppo_loss -> MLP bwd -> [RCCL all-reduce of the flat gradient bucket] -> imx_adam_step).
+value = num_envs x 24 x world_size x K / wall time (max over ranks), inputs resident in HBM before the timed region.
+
+Besides the contract line it reports
+  * env_step_path: the post-physics path alone (3 env kernels per step + GAE per 24 steps, no policy) -- the
+    like-for-like counterpart of cpu_baseline;
+  * roofline: the dominant hand-written kernel (k_obs = observation assembly + fused height-scanner ray-cast),
+    algorithmic bytes per launch / average launch duration from HIP events on the launch stream, vs the 8 TB/s peak;
+  * cpu_baseline: the CPU restatement of the reference managers + GAE (oracle/, kind "port") on this box's host
+    cores, bounded sample, rank 0, N=1 only.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TASK = "Isaac-Velocity-Rough-Anymal-C-v0"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def obs_kernel_bytes_per_env(plan) -> float:
+    """Algorithmic HBM bytes of k_obs per env-step (DESIGN.md section 'roofline'): state reads + unique terrain
+    data under the scanner footprint + the obs row written."""
+    J, A, D, R = plan.num_joints, plan.action_dim, plan.obs_dim, plan.num_rays
+    reads = (13 + 4 * J + A + 3) * 4  # root state, joint pos/vel + defaults, last action, command
+    mesh = 0.0
+    if R:
+        # unique triangles under a 1.6 x 1.0 m footprint on a 0.1 m height field: (16+1)x(10+1) cells x 2 triangles
+        # x 36 B packed corners + cell table 17x11 x 4 B + triangle ids 17x11x2 x 4 B
+        cells = 17 * 11
+        mesh = cells * 2 * 36 + cells * 4 + cells * 2 * 4
+    writes = D * 4
+    return float(reads + mesh + writes)
+
+
+def build_env(task, num_envs, device, seed, snapshots, terrain_tiles):
+    from isaaclab_amd.env import ManagerBasedRLEnv, load_task_cfg
+    from isaaclab_amd.robots import ROBOTS
+    from isaaclab_amd.state_feed import StateFeed
+    from isaaclab_amd.terrain import make_rough_terrain
+
+    fx = load_task_cfg(task)
+    robot = ROBOTS[fx["robot"]]
+    terrain = ext = None
+    ntri = 0
+    if fx["env"]["scene"].get("height_scanner") is not None:
+        v, t, e = make_rough_terrain(terrain_tiles[0], terrain_tiles[1], tile=8.0, horizontal_scale=0.1, border=20.0, seed=0)
+        terrain, ext, ntri = (v, t), (e[0] - 1.0, e[1] - 1.0), len(t)
+    feed = StateFeed(robot, num_envs, device, seed=seed, num_snapshots=snapshots, extent_xy=ext)
+    env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed)
+    return fx, env, ntri
+
+
+def time_env_path(env, runner_storage_T, iters):
+    """Post-physics path only: per step 3 env kernels, per T steps one GAE (random rewards in the storage)."""
+    from isaaclab_amd.rsl_rl.storage import gae_returns
+
+    N, T = env.num_envs, runner_storage_T
+    dev = env.device
+    act = torch.randn(N, env.plan.action_dim, device=dev).clamp_(-3, 3)
+    rew = torch.randn(T, N, 1, device=dev)
+    val = torch.randn(T, N, 1, device=dev)
+    dones = torch.zeros(T, N, 1, dtype=torch.uint8, device=dev)
+    last = torch.randn(N, 1, device=dev)
+    ret, adv = torch.empty_like(rew), torch.empty_like(rew)
+
+    def one_rollout():
+        for _ in range(T):
+            env.step(act)
+        gae_returns(rew, val, dones, last, 0.99, 0.95, True, ret, adv)
+
+    one_rollout()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one_rollout()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return N * T * iters / dt, dt / (iters * T)
+
+
+def time_obs_kernel(env, launches=200):
+    """Average duration of k_obs from HIP events on the stream it is launched on (torch's current stream)."""
+    dev = env.device
+    for _ in range(10):
+        env._compute_observations()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(launches):
+        env._compute_observations()
+    e1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / launches  # seconds per launch
+
+
+def cpu_baseline(task, num_envs, T, budget_s=12.0):
+    """oracle/ restatement of TerminationManager + RewardManager + ObservationManager (+ action affine) + GAE on
+    torch-CPU, same synthetic feed distribution (height-scan hits supplied; no ray-cast on the CPU side)."""
+    from isaaclab_amd.env import load_task_cfg
+    from isaaclab_amd.robots import ROBOTS
+    from isaaclab_amd.state_feed import StateFeed
+    from oracle.mdp_oracle import OracleEnv
+    from oracle.rsl_rl_oracle import compute_returns
+
+    fx = load_task_cfg(task)
+    robot = ROBOTS[fx["robot"]]
+    feed = StateFeed(robot, num_envs, "cpu", seed=42, num_snapshots=4)
+    env = OracleEnv(fx["env"], robot.joint_names, robot.body_names, num_envs, feed.__getitem__, feed.gravity_dir)
+    g = torch.Generator().manual_seed(0)
+    if fx["env"]["scene"].get("height_scanner") is not None:
+        env.ray_hits_w = torch.rand(num_envs, 187, 3, generator=g) * 0.2
+    act = torch.randn(num_envs, env.A, generator=g).clamp_(-3, 3)
+    rew, val = torch.randn(T, num_envs, 1, generator=g), torch.randn(T, num_envs, 1, generator=g)
+    dones = torch.zeros(T, num_envs, 1, dtype=torch.uint8)
+    last = torch.randn(num_envs, 1, generator=g)
+    env.episode_length_buf[:] = torch.randint(0, env.max_episode_length, (num_envs,), generator=g)
+
+    def step():
+        env.process_action(act)
+        feed.advance()
+        env.post_physics_step(None)
+
+    for _ in range(3):
+        step()
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(T):
+            step()
+        compute_returns(rew, val, dones, last, 0.99, 0.95, True)
+        steps += T
+    dt = time.perf_counter() - t0
+    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} env-steps of {num_envs} envs ({steps // T} rollouts incl. GAE, obs noise on, "
+                      f"height-scan hits supplied, no policy), {dt:.1f} s, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--task", default=TASK)
+    ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--snapshots", type=int, default=4)
+    ap.add_argument("--terrain-tiles", type=int, nargs=2, default=(10, 20))
+    ap.add_argument("--no-graph", action="store_true", help="eager rollout instead of one hipGraph replay per rollout")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libimx has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
+
+    torch.manual_seed(42 + rank)
+    fx, env, ntri = build_env(args.task, args.num_envs, device, 42 + rank, args.snapshots, tuple(args.terrain_tiles))
+    agent = fx["agent"]
+    venv = RslRlVecEnvWrapper(env, clip_actions=agent.get("clip_actions"))
+    runner = OnPolicyRunner(venv, agent, log_dir=None, device=str(device), use_graph=not args.no_graph)
+    T = runner.num_steps_per_env
+    venv.episode_length_buf = torch.randint_like(venv.episode_length_buf, high=int(venv.max_episode_length))
+    if world > 1:
+        runner.alg.broadcast_parameters()
+    runner.train_mode()
+
+    def iteration():
+        runner.collect()
+        with torch.inference_mode():
+            runner.alg.compute_returns(runner.last_obs)
+        runner.alg.update()
+
+    for _ in range(args.warmup):
+        iteration()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    tc = 0.0
+    for _ in range(args.steps):
+        c0 = time.perf_counter()
+        iteration()
+        tc += time.perf_counter() - c0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = args.num_envs * T * world * args.steps / elapsed
+    stats = runner.alg.loss_dict()
+
+    # --- secondary measurements on rank 0 (outside the timed region)
+    out = {
+        "metric": "env-steps/sec (whole node), Anymal-C rough 4096 envs/GPU, RSL-RL PPO iteration (collect+GAE+update)",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.task}, {args.num_envs} envs/GPU, T={T}, 5 epochs x 4 minibatches, "
+                               f"terrain {ntri} triangles, {args.snapshots} state snapshots resident in HBM",
+                   "parallelism": f"dp{world}", "rollout": "eager" if args.no_graph else "hipGraph",
+                   "policy_params": runner.alg.bucket.numel},
+    }
+    if rank == 0:
+        env_rate, env_step_s = time_env_path(env, T, iters=20)
+        k_s = time_obs_kernel(env)
+        bytes_launch = obs_kernel_bytes_per_env(env.plan) * args.num_envs
+        achieved = bytes_launch / k_s / 1e9
+        out["env_step_path"] = {"value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
+                                "what": "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
+        out["roofline"] = {"bound": "hbm", "kernel": "k_obs<8> (observations + fused height-scanner ray-cast)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
+        out["ppo"] = {k: round(v, 6) for k, v in stats.items()}
+        out["ppo"]["learning_rate"] = runner.alg.learning_rate
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.task, args.num_envs, T, args.cpu_budget)
+            out["env_step_path"]["vs_cpu_baseline"] = env_rate / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

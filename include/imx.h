@@ -250,6 +250,13 @@ int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma
                      int use_clipped_value_loss, float value_loss_coef, float entropy_coef, float grad_scale,
                      float* dmu_d, float* dsigma_d, float* dvalue_d, imx_stream_t stream);
 
+/* torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (as used by rsl_rl PPO.update) on one flat fp32 bucket.
+ * lr_d / grad_norm_d are DEVICE scalars (adaptive-KL learning rate, ||g||_2); grad_norm_d NULL = no clipping.
+ * step = 1-based Adam step count. */
+int imx_adam_step(int64_t n, float* param_d, const float* grad_d, float* exp_avg_d, float* exp_avg_sq_d,
+                  const float* lr_d, const float* grad_norm_d, float max_norm, float beta1, float beta2, float eps,
+                  int64_t step, imx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

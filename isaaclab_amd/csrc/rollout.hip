@@ -268,3 +268,39 @@ extern "C" int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu, const flo
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- Adam
+// torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step on ONE flat parameter bucket, with the learning rate and
+// the gradient norm read from device memory (no host round trip for the adaptive-KL schedule).
+//   clip_coef = min(1, max_norm / (norm + 1e-6));  g *= clip_coef
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= lr/bias1 * m / (sqrt(v)/sqrt(bias2) + eps)
+__global__ void __launch_bounds__(256)
+k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+       const float* __restrict__ lr_d, const float* __restrict__ norm_d, float max_norm, float b1, float b2, float eps,
+       float bias1, float sqrt_bias2) {
+    const float lr = lr_d[0];
+    float coef = 1.0f;
+    if (norm_d) coef = fminf(max_norm / (norm_d[0] + 1.0e-6f), 1.0f);
+    const float step_size = lr / bias1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / sqrt_bias2 + eps));
+    }
+}
+
+extern "C" int imx_adam_step(int64_t n, float* p, const float* g, float* m, float* v, const float* lr_d,
+                             const float* grad_norm_d, float max_norm, float beta1, float beta2, float eps,
+                             int64_t step, imx_stream_t stream) {
+    IMX_REQUIRE(n > 0 && p && g && m && v && lr_d && step > 0, "imx_adam_step: bad arguments");
+    const float bias1 = 1.0f - powf(beta1, (float)step);
+    const float sb2 = sqrtf(1.0f - powf(beta2, (float)step));
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, lr_d, grad_norm_d, max_norm,
+                       beta1, beta2, eps, bias1, sb2);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

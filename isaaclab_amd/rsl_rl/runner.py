@@ -1,0 +1,200 @@
+"""``OnPolicyRunner`` (upstream ``rsl_rl/runners/on_policy_runner.py`` @ v2.3.1 -- third-party, absent from the
+reference tree; call sites: reference scripts/reinforcement_learning/rsl_rl/train.py:167-183, play.py:115-134).
+
+One process per GPU.  ``learn()`` = per iteration: T env steps (policy act -> env.step -> storage), GAE, PPO update.
+The whole T-step rollout can be captured once into a hipGraph (``use_graph=True``) and replayed: the env kernels are
+launched on torch's capturing stream, the state feed's snapshot pointers and the storage slots are baked per step.
+Episode statistics stay on the device; nothing in the loop synchronises with the host unless logging asks for it.
+"""
+
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .actor_critic import ActorCritic
+from .ppo import PPO
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg: dict, log_dir: str | None = None, device="cpu", use_graph: bool = False):
+        self.cfg = train_cfg
+        self.alg_cfg = dict(train_cfg["algorithm"])
+        self.policy_cfg = dict(train_cfg["policy"])
+        self.device = torch.device(device)
+        self.env = env
+        self._configure_multi_gpu()
+        obs, extras = self.env.get_observations()
+        num_obs = obs.shape[1]
+        num_privileged_obs = extras["observations"]["critic"].shape[1] if "critic" in extras["observations"] else num_obs
+        self.privileged_obs_type = "critic" if "critic" in extras["observations"] else None
+        self.policy_cfg.pop("class_name", None)
+        policy = ActorCritic(num_obs, num_privileged_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
+        self.alg_cfg.pop("class_name", None)
+        self.alg = PPO(policy, device=self.device, multi_gpu_cfg=self.multi_gpu_cfg, **self.alg_cfg)
+        self.num_steps_per_env = int(train_cfg["num_steps_per_env"])
+        self.save_interval = int(train_cfg.get("save_interval", 50))
+        if train_cfg.get("empirical_normalization", False):
+            raise NotImplementedError("EmpiricalNormalization is a SURVEY 8f 'next' row (policy side)")
+        self.obs_normalizer = torch.nn.Identity().to(self.device)
+        self.privileged_obs_normalizer = torch.nn.Identity().to(self.device)
+        self.alg.init_storage("rl", self.env.num_envs, self.num_steps_per_env, [num_obs], [num_privileged_obs],
+                              [self.env.num_actions])
+        self.disable_logs = self.is_distributed and self.gpu_global_rank != 0
+        self.log_dir = log_dir
+        self.current_learning_iteration = 0
+        self.tot_timesteps = 0
+        self.tot_time = 0.0
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._graph = None
+        N = self.env.num_envs
+        self._cur_reward_sum = torch.zeros(N, device=self.device)
+        self._cur_episode_length = torch.zeros(N, device=self.device)
+        self._ep_stats = torch.zeros(3, device=self.device)  # finished episodes: sum reward, sum length, count
+        self._obs = obs
+        self.collection_time = self.learn_time = 0.0
+
+    # ---- distributed ---------------------------------------------------------------------------------------------
+    def _configure_multi_gpu(self):
+        self.gpu_world_size = int(os.getenv("WORLD_SIZE", "1"))
+        self.is_distributed = self.gpu_world_size > 1
+        if not self.is_distributed:
+            self.gpu_local_rank = self.gpu_global_rank = 0
+            self.multi_gpu_cfg = None
+            return
+        self.gpu_local_rank = int(os.getenv("LOCAL_RANK", "0"))
+        self.gpu_global_rank = int(os.getenv("RANK", "0"))
+        self.multi_gpu_cfg = {"global_rank": self.gpu_global_rank, "local_rank": self.gpu_local_rank,
+                              "world_size": self.gpu_world_size}
+        if self.device.type == "cuda" and self.device.index is not None and self.device.index != self.gpu_local_rank:
+            raise ValueError(f"Device '{self.device}' does not match expected device for local rank '{self.gpu_local_rank}'.")
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl" if self.device.type == "cuda" else "gloo", rank=self.gpu_global_rank,
+                                    world_size=self.gpu_world_size)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.gpu_local_rank)
+
+    # ---- rollout ---------------------------------------------------------------------------------------------------
+    def _rollout(self):
+        obs = self._obs
+        for _ in range(self.num_steps_per_env):
+            actions = self.alg.act(obs, obs)
+            obs, rewards, dones, infos = self.env.step(actions)
+            self.alg.process_env_step(rewards, dones, infos)
+            # episode book-keeping on the device (upstream pulls finished episodes to the host every step)
+            self._cur_reward_sum += rewards
+            self._cur_episode_length += 1
+            done_f = dones.to(torch.float32)
+            self._ep_stats[0] += (self._cur_reward_sum * done_f).sum()
+            self._ep_stats[1] += (self._cur_episode_length * done_f).sum()
+            self._ep_stats[2] += done_f.sum()
+            self._cur_reward_sum *= 1.0 - done_f
+            self._cur_episode_length *= 1.0 - done_f
+        if self._graph_capturing:
+            self._obs_out.copy_(obs)
+        return obs
+
+    _graph_capturing = False
+
+    def collect(self):
+        """One rollout of ``num_steps_per_env`` env steps into the storage (eager, or one hipGraph replay)."""
+        with torch.inference_mode():
+            if not self.use_graph:
+                self._obs = self._rollout()
+                return
+            if self._graph is None:
+                # warm up eagerly on a side stream (allocator, lazy inits), then capture the same sequence once
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    self._obs = self._rollout()
+                    self.alg.storage.clear()
+                torch.cuda.current_stream(self.device).wait_stream(s)
+                torch.cuda.synchronize(self.device)
+                self._obs_in = self._obs.clone()
+                self._obs_out = torch.empty_like(self._obs)
+                self._obs = self._obs_in
+                self._graph = torch.cuda.CUDAGraph()
+                self._graph_capturing = True
+                feed_idx = self.env.unwrapped.feed.index
+                with torch.cuda.graph(self._graph):
+                    self._rollout()
+                self._graph_capturing = False
+                if self.env.unwrapped.feed.index != feed_idx:
+                    raise RuntimeError("rollout graph needs num_steps_per_env to be a multiple of the feed's snapshot count")
+                self._obs = self._obs_in
+            else:
+                self._obs_in.copy_(self._obs_out)
+            self._graph.replay()
+            self.alg.storage.step = self.num_steps_per_env
+            self.env.unwrapped.common_step_counter += self.num_steps_per_env
+
+    @property
+    def last_obs(self):
+        return self._obs_out if self.use_graph else self._obs
+
+    def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False):
+        if init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        self.train_mode()
+        if self.is_distributed:
+            self.alg.broadcast_parameters()
+        start_iter = self.current_learning_iteration
+        for it in range(start_iter, start_iter + num_learning_iterations):
+            t0 = time.perf_counter()
+            self.collect()
+            with torch.inference_mode():
+                self.alg.compute_returns(self.last_obs)
+            t1 = time.perf_counter()
+            self.alg.update()
+            t2 = time.perf_counter()
+            self.collection_time, self.learn_time = t1 - t0, t2 - t1
+            self.current_learning_iteration = it + 1
+            self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.gpu_world_size
+            if self.log_dir is not None and not self.disable_logs and (it + 1) % self.save_interval == 0:
+                self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
+
+    def episode_stats(self) -> dict:
+        s = self._ep_stats.tolist()
+        n = max(s[2], 1.0)
+        return {"mean_reward": s[0] / n, "mean_episode_length": s[1] / n, "episodes": s[2]}
+
+    # ---- checkpoint / inference (train.py / play.py surface) ---------------------------------------------------
+    def save(self, path: str, infos=None):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save({"model_state_dict": self.alg.policy.state_dict(),
+                    "optimizer_state_dict": {"exp_avg": self.alg.bucket.exp_avg, "exp_avg_sq": self.alg.bucket.exp_avg_sq,
+                                             "step": self.alg.bucket.step, "lr": self.alg._lr},
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path: str, load_optimizer: bool = True):
+        d = torch.load(path, weights_only=True, map_location=self.device)
+        with torch.no_grad():
+            for k, v in d["model_state_dict"].items():
+                self.alg.policy.state_dict()[k].copy_(v)  # in place: parameters stay views of the flat bucket
+        if load_optimizer and "optimizer_state_dict" in d:
+            o = d["optimizer_state_dict"]
+            self.alg.bucket.exp_avg.copy_(o["exp_avg"])
+            self.alg.bucket.exp_avg_sq.copy_(o["exp_avg_sq"])
+            self.alg.bucket.step = int(o["step"])
+            self.alg._lr.copy_(o["lr"])
+        self.current_learning_iteration = d.get("iter", 0)
+        return d.get("infos")
+
+    def get_inference_policy(self, device=None):
+        self.eval_mode()
+        if device is not None:
+            self.alg.policy.to(device)
+        return self.alg.policy.act_inference
+
+    def train_mode(self):
+        self.alg.policy.train()
+
+    def eval_mode(self):
+        self.alg.policy.eval()
+
+    def add_git_repo_to_log(self, repo_file_path):
+        pass

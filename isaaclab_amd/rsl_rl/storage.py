@@ -1,0 +1,115 @@
+"""Rollout storage + GAE for the RSL-RL PPO rollout (upstream ``rsl_rl/storage/rollout_storage.py`` @ v2.3.1, a
+third-party dependency absent from the reference tree -- PARITY UNPINNED, see oracle/rsl_rl_oracle.py).
+
+Buffers are preallocated ``(T, N, .)`` tensors that stay resident in HBM for the whole run (fixed pointers: the
+rollout can be captured in a hipGraph); the GAE backward scan and the advantage normalisation are ``imx_gae``.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from .._lib import check, lib
+
+
+def gae_returns(rewards, values, dones, last_values, gamma: float, lam: float, normalize: bool = True,
+                returns=None, advantages=None, scratch=None):
+    """``RolloutStorage.compute_returns``: (T,N,1) rewards/values/dones(uint8) + (N,1) last values -> returns, advantages."""
+    T, N = rewards.shape[0], rewards.shape[1]
+    dev = rewards.device
+    if returns is None:
+        returns = torch.empty_like(rewards)
+    if advantages is None:
+        advantages = torch.empty_like(rewards)
+    L = lib()
+    if scratch is None:
+        scratch = torch.empty(int(L.imx_gae_scratch_bytes(T, N)), dtype=torch.uint8, device=dev)
+    if dones.dtype not in (torch.uint8, torch.bool):
+        raise TypeError("dones must be uint8/bool")
+    check(L.imx_gae(T, N, _lib.ptr(rewards), _lib.ptr(values), _lib.ptr(dones), _lib.ptr(last_values), float(gamma),
+                    float(lam), 1 if normalize else 0, _lib.ptr(returns), _lib.ptr(advantages), _lib.ptr(scratch),
+                    _lib.current_stream(dev)))
+    return returns, advantages
+
+
+class RolloutStorage:
+    class Transition:
+        def __init__(self):
+            self.observations = None
+            self.privileged_observations = None
+            self.actions = None
+            self.rewards = None
+            self.dones = None
+            self.values = None
+            self.actions_log_prob = None
+            self.action_mean = None
+            self.action_sigma = None
+
+        def clear(self):
+            self.__init__()
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, actions_shape, device="cpu"):
+        self.device = device
+        self.num_envs = num_envs
+        self.num_transitions_per_env = T = num_transitions_per_env
+        N = num_envs
+        z = lambda *s, **k: torch.zeros(*s, device=device, **k)  # noqa: E731
+        self.observations = z(T, N, *obs_shape)
+        self.privileged_observations = z(T, N, *privileged_obs_shape) if privileged_obs_shape and privileged_obs_shape[0] else None
+        self.rewards = z(T, N, 1)
+        self.actions = z(T, N, *actions_shape)
+        self.dones = z(T, N, 1, dtype=torch.uint8)
+        self.actions_log_prob = z(T, N, 1)
+        self.values = z(T, N, 1)
+        self.returns = z(T, N, 1)
+        self.advantages = z(T, N, 1)
+        self.mu = z(T, N, *actions_shape)
+        self.sigma = z(T, N, *actions_shape)
+        self._gae_scratch = None
+        self.step = 0
+
+    def add_transitions(self, transition: "RolloutStorage.Transition"):
+        if self.step >= self.num_transitions_per_env:
+            raise OverflowError("Rollout buffer overflow! You should call clear() before adding new transitions.")
+        t = self.step
+        self.observations[t].copy_(transition.observations)
+        if self.privileged_observations is not None:
+            self.privileged_observations[t].copy_(transition.privileged_observations)
+        self.actions[t].copy_(transition.actions)
+        self.rewards[t].copy_(transition.rewards.view(-1, 1))
+        self.dones[t].copy_(transition.dones.view(-1, 1))
+        self.values[t].copy_(transition.values)
+        self.actions_log_prob[t].copy_(transition.actions_log_prob.view(-1, 1))
+        self.mu[t].copy_(transition.action_mean)
+        self.sigma[t].copy_(transition.action_sigma)
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam, normalize_advantage: bool = True):
+        if self._gae_scratch is None:
+            n = int(lib().imx_gae_scratch_bytes(self.num_transitions_per_env, self.num_envs))
+            self._gae_scratch = torch.empty(n, dtype=torch.uint8, device=self.device)
+        gae_returns(self.rewards, self.values, self.dones, last_values.contiguous(), gamma, lam, normalize_advantage,
+                    self.returns, self.advantages, self._gae_scratch)
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        batch_size = self.num_envs * self.num_transitions_per_env
+        mini_batch_size = batch_size // num_mini_batches
+        indices = torch.randperm(num_mini_batches * mini_batch_size, requires_grad=False, device=self.device)
+        observations = self.observations.flatten(0, 1)
+        privileged = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else observations
+        actions = self.actions.flatten(0, 1)
+        values = self.values.flatten(0, 1)
+        returns = self.returns.flatten(0, 1)
+        old_logp = self.actions_log_prob.flatten(0, 1)
+        advantages = self.advantages.flatten(0, 1)
+        old_mu = self.mu.flatten(0, 1)
+        old_sigma = self.sigma.flatten(0, 1)
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = indices[i * mini_batch_size:(i + 1) * mini_batch_size]
+                yield (observations[idx], privileged[idx], actions[idx], values[idx], advantages[idx], returns[idx],
+                       old_logp[idx], old_mu[idx], old_sigma[idx])

@@ -1,0 +1,121 @@
+"""GPU: standalone kernels through the C ABI -- root frame, ray-cast, GAE, PPO loss."""
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import FLOAT_TOL, GOLDEN, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_root_frame_matches_reference_math(libimx):
+    from isaaclab_amd import _lib
+
+    z = np.load(os.path.join(GOLDEN, "math.npz"))
+    q, v = torch.from_numpy(z["q"]).cuda(), torch.from_numpy(z["v"]).cuda()
+    out = torch.empty_like(v)
+    g = torch.empty_like(v)
+    _lib.check(libimx.imx_root_frame(q.shape[0], q.data_ptr(), v.data_ptr(), None, 0.0, 0.0, -1.0, out.data_ptr(), None,
+                                     g.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert_close(out, torch.from_numpy(z["quat_rotate_inverse"]), 1e-6, "quat_rotate_inverse")
+
+
+def test_raycast_matches_brute_force_oracles():
+    from isaaclab_amd.env import TerrainMesh
+    from isaaclab_amd.terrain import make_rough_terrain
+    from oracle.raycast import raycast_f64, raycast_woop_f32
+
+    v, t, ext = make_rough_terrain(2, 3, tile=4.0, border=2.0, seed=21)
+    rng = np.random.default_rng(0)
+    R = 20000
+    starts = np.stack([rng.uniform(-7, 7, R), rng.uniform(-9, 9, R), rng.uniform(19, 21, R)], 1).astype(np.float32)
+    # lattice-aligned rays too: exactly on vertices / edges of the height field
+    starts[:2000, 0] = np.round(starts[:2000, 0] * 10) / 10
+    starts[1000:3000, 1] = np.round(starts[1000:3000, 1] * 10) / 10
+    dirs = np.tile(np.array([0, 0, -1], np.float32), (R, 1))
+    for cell in (0.1, 0.0, 0.37):
+        mesh = TerrainMesh(v, t, cell)
+        hits, dist, _, face = mesh.raycast(torch.from_numpy(starts).cuda(), torch.from_numpy(dirs).cuda(), 1e6, True, True)
+        h32, t32, f32 = raycast_woop_f32(v, t, starts, dirs)
+        h64, t64, f64 = raycast_f64(v, t, starts, dirs)
+        hits, dist, face = hits.cpu().numpy(), dist.cpu().numpy(), face.cpu().numpy()
+        miss = ~np.isfinite(t32)
+        assert np.array_equal(~np.isfinite(dist), miss), f"cell={cell}: miss masks differ"
+        assert miss.sum() < R // 10
+        # same fp32 arithmetic as the Woop oracle: bit-exact distances; the fp64 geometric truth within 1e-5
+        assert np.array_equal(dist[~miss], t32[~miss]), f"cell={cell}"
+        assert np.abs(hits[~miss] - h64[~miss]).max() <= 1e-5
+        assert mesh.num_triangles == len(t)
+    # general (slanted) rays through the DDA path
+    R2 = 4000
+    s2 = np.stack([rng.uniform(-5, 5, R2), rng.uniform(-7, 7, R2), rng.uniform(0.5, 3, R2)], 1).astype(np.float32)
+    d2 = rng.normal(size=(R2, 3)).astype(np.float32)
+    d2[:, 2] = -np.abs(d2[:, 2]) * 0.3
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    mesh = TerrainMesh(v, t, 0.1)
+    hits, dist, _, face = mesh.raycast(torch.from_numpy(s2).cuda(), torch.from_numpy(d2).cuda(), 50.0, True, True)
+    h64, t64, f64 = raycast_f64(v, t, s2, d2, 50.0)
+    dist = dist.cpu().numpy()
+    both = np.isfinite(dist) & np.isfinite(t64)
+    assert (np.isfinite(dist) != np.isfinite(t64)).mean() < 2e-3  # grazing rays at max_dist / silhouette edges
+    assert np.abs(dist[both] - t64[both]).max() <= 1e-3 and np.median(np.abs(dist[both] - t64[both])) <= 1e-5
+    # empty input
+    e = torch.empty(0, 3, device="cuda")
+    assert mesh.raycast(e, e)[0].shape == (0, 3)
+
+
+@pytest.mark.parametrize("T,N", [(24, 4096), (16, 64), (5, 1), (24, 100_001)])
+def test_gae_matches_rsl_rl_restatement(libimx, T, N):
+    from isaaclab_amd.rsl_rl.storage import gae_returns
+    from oracle.rsl_rl_oracle import compute_returns
+
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    rew = torch.randn(T, N, 1, generator=g)
+    val = torch.randn(T, N, 1, generator=g)
+    dones = (torch.rand(T, N, 1, generator=g) < 0.05).to(torch.uint8)
+    last = torch.randn(N, 1, generator=g)
+    for norm in (True, False):
+        if N * T == 5 and norm:
+            pass
+        ret0, adv0 = compute_returns(rew, val, dones, last, 0.99, 0.95, norm)
+        ret1, adv1 = gae_returns(rew.cuda(), val.cuda(), dones.cuda(), last.cuda(), 0.99, 0.95, norm)
+        assert_close(ret1, ret0, FLOAT_TOL, "returns")
+        assert_close(adv1, adv0, FLOAT_TOL, "advantages")
+    # property: with gamma*lam = 0 the advantage is the one-step TD error
+    ret, adv = gae_returns(rew.cuda(), val.cuda(), dones.cuda(), last.cuda(), 0.9, 0.0, False)
+    nv = torch.cat([val[1:], last.unsqueeze(0)], 0)
+    td = rew + (1 - dones.float()) * 0.9 * nv - val
+    assert_close(adv, td, FLOAT_TOL, "TD(0)")
+
+
+@pytest.mark.parametrize("M,A", [(24576, 12), (1000, 37), (7, 1)])
+def test_ppo_loss_matches_autograd(libimx, M, A):
+    from isaaclab_amd.rsl_rl.ppo import fused_ppo_loss
+    from oracle.rsl_rl_oracle import ppo_losses
+
+    g = torch.Generator().manual_seed(M + A)
+    mu = torch.randn(M, A, generator=g)
+    sigma = torch.rand(M, A, generator=g) * 0.8 + 0.3
+    act = mu + sigma * torch.randn(M, A, generator=g)
+    old_mu = mu + 0.1 * torch.randn(M, A, generator=g)
+    old_sigma = sigma * (1 + 0.1 * torch.randn(M, A, generator=g)).clamp(0.5, 1.5)
+    old_logp = torch.distributions.Normal(old_mu, old_sigma).log_prob(act).sum(-1, keepdim=True)
+    adv, ret, val, old_val = (torch.randn(M, 1, generator=g) for _ in range(4))
+    for clipped in (True, False):
+        mu_c, sg_c, v_c = (x.clone().requires_grad_(True) for x in (mu, sigma, val))
+        s, v, e, kl = ppo_losses(mu_c, sg_c, act, old_logp, old_mu, old_sigma, adv, ret, v_c, old_val, 0.2, clipped)
+        loss = s + 1.0 * v - 0.005 * e
+        loss.backward()
+        mu_g, sg_g, v_g = (x.clone().cuda().requires_grad_(True) for x in (mu, sigma, val))
+        loss_g, stats = fused_ppo_loss(mu_g, sg_g, act.cuda(), old_logp.cuda(), old_mu.cuda(), old_sigma.cuda(), adv.cuda(),
+                                       ret.cuda(), v_g, old_val.cuda(), 0.2, clipped, 1.0, 0.005)
+        loss_g.backward()
+        assert_close(stats[:4], torch.stack([s, v, e, kl]).detach(), FLOAT_TOL, "loss terms")
+        assert_close(loss_g.detach(), loss.detach(), FLOAT_TOL, "loss")
+        assert_close(mu_g.grad * M, mu_c.grad * M, 1e-4, "dmu")
+        assert_close(sg_g.grad * M, sg_c.grad * M, 1e-4, "dsigma")
+        assert_close(v_g.grad * M, v_c.grad * M, 1e-4, "dvalue")
