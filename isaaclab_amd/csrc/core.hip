@@ -172,7 +172,39 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
     for (int c = 0; c < p->D; ++c)
         if (w[p->obs_off + (col[c] >> 16) * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) p->n_ray_cols++;
     w.insert(w.end(), order.begin(), order.end());
+    // reward slots without a record (zero-weight terms): they still take part in the reset/log pass
+    {
+        std::vector<char> has(p->nrew_all > 0 ? p->nrew_all : 1, 0);
+        for (int k = 0; k < p->nrew; ++k) {
+            const int idx = w[p->rew_off + k * IMX_REC_WORDS + IMX_R_OUT];
+            IMX_REQUIRE(!has[idx], "plan: reward slot %d has two records", idx);
+            has[idx] = 1;
+        }
+        p->skip_off = (int)w.size();
+        for (int i = 0; i < p->nrew_all; ++i)
+            if (!has[i]) { w.push_back(i); p->nskip++; }
+    }
 
+    // per-column expansion (see step.hip: XC_*), 16-byte aligned, in `order`
+    while (w.size() % 4) w.push_back(0);
+    p->xcol_off = (int)w.size();
+    for (int i = 0; i < p->D; ++i) {
+        const int c = order[i], k = col[c] >> 16, j = col[c] & 0xFFFF;
+        const size_t ro = (size_t)p->obs_off + (size_t)k * IMX_REC_WORDS;  // index: w reallocates while we append
+        int32_t x[16] = {0};
+        x[0] = c; x[1] = w[ro + IMX_R_OP]; x[2] = j; x[3] = w[ro + IMX_R_FLAGS];
+        x[4] = w[ro + IMX_R_P0]; x[5] = w[ro + IMX_R_NOISE_LO]; x[6] = w[ro + IMX_R_NOISE_HI];
+        x[7] = w[ro + IMX_R_CLIP_LO]; x[8] = w[ro + IMX_R_CLIP_HI]; x[9] = w[ro + IMX_R_SCALE];
+        const int op = x[1];
+        const bool joint = op == IMX_O_JOINT_POS || op == IMX_O_JOINT_POS_REL || op == IMX_O_JOINT_VEL ||
+                           op == IMX_O_JOINT_VEL_REL || op == IMX_O_JOINT_POS_LIMIT_NORMALIZED;
+        if (joint) x[10] = w[(size_t)w[ro + IMX_R_IDS_OFF] + j];
+        if (op == IMX_O_EXTERNAL) x[10] = w[ro + IMX_R_AUX0];
+        if (op == IMX_O_HEIGHT_SCAN) {
+            x[11] = w[(size_t)p->ray_off + 3 * j]; x[12] = w[(size_t)p->ray_off + 3 * j + 1]; x[13] = w[(size_t)p->ray_off + 3 * j + 2];
+        }
+        w.insert(w.end(), x, x + 16);
+    }
     if (imx_device_count() > 0) {
         IMX_HIP(hipMalloc((void**)&p->dev, w.size() * sizeof(int32_t)));
         IMX_HIP(hipMemcpy(p->dev, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -197,6 +229,7 @@ PlanView imx_plan_view(const imx_plan* p) {
     v.nterm = p->nterm; v.nrew = p->nrew; v.nobs = p->nobs; v.nact = p->nact; v.nrew_all = p->nrew_all;
     v.term_off = p->term_off; v.rew_off = p->rew_off; v.obs_off = p->obs_off; v.act_off = p->act_off;
     v.ray_off = p->ray_off; v.col_off = p->col_off; v.order_off = p->order_off; v.n_ray_cols = p->n_ray_cols;
+    v.skip_off = p->skip_off; v.nskip = p->nskip; v.xcol_off = p->xcol_off;
     v.max_ep_len = w[IMX_H_MAX_EP_LEN];
     v.step_dt = wf(w[IMX_H_STEP_DT]);
     v.max_ep_len_s = wf(w[IMX_H_MAX_EP_LEN_S]);

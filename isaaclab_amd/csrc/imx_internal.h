@@ -40,6 +40,8 @@ struct imx_plan {
     int col_off = 0;    // D words: (obs record index << 16) | local index j
     int order_off = 0;  // D words: column permutation, ray columns first
     int n_ray_cols = 0;
+    int skip_off = 0, nskip = 0;  // reward slots with no record (zero weight)
+    int xcol_off = 0;             // D x 16 words: per-column expansion of the obs records, ray columns first
     bool needs_mesh = false;
 };
 
@@ -48,7 +50,7 @@ struct PlanView {
     const int32_t* w;  // device blob
     int J, B, H, A, D, R, NB, CMD;
     int nterm, nrew, nobs, nact, nrew_all;
-    int term_off, rew_off, obs_off, act_off, ray_off, col_off, order_off, n_ray_cols;
+    int term_off, rew_off, obs_off, act_off, ray_off, col_off, order_off, n_ray_cols, skip_off, nskip, xcol_off;
     int max_ep_len;
     float step_dt, max_ep_len_s;
     float gx, gy, gz;
@@ -59,21 +61,29 @@ PlanView imx_plan_view(const imx_plan* p);
 
 // ---- mesh ---------------------------------------------------------------------------------------------------------
 struct MeshView {
-    const float* tri_verts;     // (F,9) xyz of the three corners
-    const int32_t* cell_start;  // (nx*ny + 1)
-    const int32_t* cell_tris;   // (num refs) triangle ids, grouped per cell
+    // (num refs, 12) per-cell triangle records, grouped per cell: ax ay az bx | by bz cx cy | cz face(int) 0 0.
+    // 48 B = three 16-byte loads, no triangle-id indirection; a height-field mesh aligned with the grid has one
+    // reference per triangle, so nothing is duplicated in the common case.
+    const float4* tri_rec;
+    // (ntx*nty*64 + 1): cells are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height
+    // scanner maps to a handful of 6 KB runs instead of 17 row segments 190 KB apart
+    const int32_t* cell_start;
+    int ntx, nty;
     int nx, ny;
     float x0, y0, cell, inv_cell;
     int64_t F;
 };
 struct imx_mesh {
     MeshView v{};
-    float* d_tri_verts = nullptr;
+    float4* d_tri_rec = nullptr;
     int32_t* d_cell_start = nullptr;
-    int32_t* d_cell_tris = nullptr;
     int64_t num_refs = 0;
     int32_t max_refs = 0;
 };
+// linear index of cell (ix, iy) in the 8x8-tiled layout
+static __host__ __device__ __forceinline__ int imx_cell_index(int ix, int iy, int ntx) {
+    return (((iy >> 3) * ntx + (ix >> 3)) << 6) | ((iy & 7) << 3) | (ix & 7);
+}
 #define IMX_GRID_TAU 1.0e-3f  // boundary snap tolerance in cell units (see raycast.hip)
 
 // ---- device helpers ------------------------------------------------------------------------------------------------

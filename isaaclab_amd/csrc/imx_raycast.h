@@ -49,11 +49,12 @@ IMX_DEV WoopRay woop_setup(float ox, float oy, float oz, float dx, float dy, flo
     return r;
 }
 
-// tv: 9 floats (a, b, c corners)
-IMX_DEV bool woop_hit(const WoopRay& r, const float* __restrict__ tv, float& t) {
-    const float a0 = tv[0] - r.ox, a1 = tv[1] - r.oy, a2 = tv[2] - r.oz;
-    const float b0 = tv[3] - r.ox, b1 = tv[4] - r.oy, b2 = tv[5] - r.oz;
-    const float c0 = tv[6] - r.ox, c1 = tv[7] - r.oy, c2 = tv[8] - r.oz;
+// corners a, b, c of one triangle
+IMX_DEV bool woop_hit(const WoopRay& r, float ax, float ay, float az, float bx_, float by_, float bz_, float cx_,
+                      float cy_, float cz_, float& t) {
+    const float a0 = ax - r.ox, a1 = ay - r.oy, a2 = az - r.oz;
+    const float b0 = bx_ - r.ox, b1 = by_ - r.oy, b2 = bz_ - r.oz;
+    const float c0 = cx_ - r.ox, c1 = cy_ - r.oy, c2 = cz_ - r.oz;
     const float Akz = pick3(a0, a1, a2, r.kz), Bkz = pick3(b0, b1, b2, r.kz), Ckz = pick3(c0, c1, c2, r.kz);
     const float Ax = pick3(a0, a1, a2, r.kx) - r.Sx * Akz, Ay = pick3(a0, a1, a2, r.ky) - r.Sy * Akz;
     const float Bx = pick3(b0, b1, b2, r.kx) - r.Sx * Bkz, By = pick3(b0, b1, b2, r.ky) - r.Sy * Bkz;
@@ -76,19 +77,30 @@ IMX_DEV bool woop_hit(const WoopRay& r, const float* __restrict__ tv, float& t) 
     return true;
 }
 
+IMX_DEV void test_record(const WoopRay& r, const float4 q0, const float4 q1, const float4 q2, float& best, int32_t& face) {
+    float t;
+    if (woop_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, t)) {
+        if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+            best = t;
+            face = __float_as_int(q2.y);
+        }
+    }
+}
+
 IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
-    const int c = iy * m.nx + ix;
+    const int c = imx_cell_index(ix, iy, m.ntx);
     const int s = m.cell_start[c], e = m.cell_start[c + 1];
-    for (int k = s; k < e; ++k) {
-        const int32_t f = m.cell_tris[k];
-        float t;
-        if (woop_hit(r, m.tri_verts + (size_t)f * 9, t)) {
-            if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
-                best = t;
-                face = f;
-            }
-        }
+    // two records per trip: their six 16-byte loads are independent and issue back to back (the usual cell of a
+    // height-field mesh holds exactly two triangles)
+    for (int k = s; k < e; k += 2) {
+        const int k1 = min(k + 1, e - 1);  // duplicate of k when the count is odd: closest-hit is idempotent
+        const float4* p0 = m.tri_rec + (size_t)k * 3;
+        const float4* p1 = m.tri_rec + (size_t)k1 * 3;
+        const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2];
+        const float4 b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        test_record(r, a0, a1, a2, best, face);
+        test_record(r, b0, b1, b2, best, face);
     }
 }
 
@@ -98,6 +110,63 @@ IMX_DEV int cell_of(float g, int& nb) {
     const float fr = g - fl;
     nb = (fr < IMX_GRID_TAU) ? -1 : ((fr > 1.0f - IMX_GRID_TAU) ? 1 : 0);
     return (int)fl;
+}
+
+// Register-lean closest hit for a VERTICAL ray (dx = dy = 0): the Woop shear terms vanish (Sx = Sy = -+0, so
+// A[kx] - Sx*A[kz] == A[kx] bit for bit) and one 48-byte record is live at a time.  Same results as cast_ray().
+IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz,
+                           float& best, int32_t& face) {
+    if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
+    const int c = imx_cell_index(ix, iy, m.ntx);
+    const int s = m.cell_start[c], e = m.cell_start[c + 1];
+    for (int k = s; k < e; ++k) {
+        const float4* p = m.tri_rec + (size_t)k * 3;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        // kx, ky = (y, x) when dz < 0 (flip), (x, y) otherwise
+        const float ax = q0.x - ox, ay = q0.y - oy, bx = q0.w - ox, by = q1.x - oy, cx = q1.z - ox, cy = q1.w - oy;
+        const float Ax = flip ? ay : ax, Ay = flip ? ax : ay;
+        const float Bx = flip ? by : bx, By = flip ? bx : by;
+        const float Cx = flip ? cy : cx, Cy = flip ? cx : cy;
+        float U = Cx * By - Cy * Bx;
+        float V = Ax * Cy - Ay * Cx;
+        float W = Bx * Ay - By * Ax;
+        if (U == 0.0f || V == 0.0f || W == 0.0f) {
+            U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+            V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+            W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+        }
+        if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
+        const float det = U + V + W;
+        if (det == 0.0f) continue;
+        const float Az = Sz * (q0.z - oz), Bz = Sz * (q1.y - oz), Cz = Sz * (q2.x - oz);
+        const float T = U * Az + V * Bz + W * Cz;
+        if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) continue;
+        const float t = T * (1.0f / det);
+        if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+            best = t;
+            face = __float_as_int(q2.y);
+        }
+    }
+}
+
+IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, float dz, float max_dist, float& t_hit,
+                               int32_t& face) {
+    float best = max_dist;
+    face = -1;
+    const bool flip = dz < 0.0f;
+    const float Sz = 1.0f / dz;
+    int nbx, nby;
+    const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
+    const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);
+    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, best, face);
+    if (nbx | nby) {  // within tau of a cell boundary (rare): the neighbouring cells as well
+        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, best, face);
+        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, best, face);
+        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, best, face);
+    }
+    if (face < 0) return false;
+    t_hit = best;
+    return true;
 }
 
 // Closest hit with t in [0, max_dist]; returns false on a miss.

@@ -44,16 +44,17 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     }
     const double ex = (double)xmax - xmin, ey = (double)ymax - ymin;
     int64_t nx = (int64_t)std::floor(ex / cell_size) + 1, ny = (int64_t)std::floor(ey / cell_size) + 1;
-    while (nx * ny > (1ll << 27)) {  // cap the table at 128 M cells
+    while (((nx + 7) / 8) * ((ny + 7) / 8) * 64 > (1ll << 27)) {  // cap the table at 128 M cells
         cell_size *= 2.0f;
         nx = (int64_t)std::floor(ex / cell_size) + 1;
         ny = (int64_t)std::floor(ey / cell_size) + 1;
     }
     const float inv_cell = 1.0f / cell_size;
-    const int64_t ncell = nx * ny;
+    const int ntx = (int)((nx + 7) / 8), nty = (int)((ny + 7) / 8);
+    const int64_t ncell = (int64_t)ntx * nty * 64;  // 8x8-tiled layout (imx_cell_index)
 
     std::vector<int32_t> start((size_t)ncell + 1, 0);
-    std::vector<float> tv((size_t)F * 9);
+    std::vector<float> tv((size_t)F * 9);  // host copy of the corners, packed per reference below
     std::vector<int32_t> ra((size_t)F * 4);  // per-triangle cell ranges
     for (int64_t f = 0; f < F; ++f) {
         float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
@@ -68,7 +69,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         cell_range(loy, hiy, ymin, inv_cell, (int)ny, ay, by);
         ra[f * 4 + 0] = ax; ra[f * 4 + 1] = bx; ra[f * 4 + 2] = ay; ra[f * 4 + 3] = by;
         for (int iy = ay; iy <= by; ++iy)
-            for (int ix = ax; ix <= bx; ++ix) start[(size_t)iy * nx + ix + 1]++;
+            for (int ix = ax; ix <= bx; ++ix) start[(size_t)imx_cell_index(ix, iy, ntx) + 1]++;
     }
     int32_t max_refs = 0;
     for (int64_t c = 0; c < ncell; ++c) {
@@ -77,24 +78,27 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         start[c + 1] += start[c];
     }
     const int64_t nrefs = start[ncell];
-    std::vector<int32_t> refs((size_t)std::max<int64_t>(nrefs, 1));
+    // per-reference 48-byte records (see MeshView): ascending triangle id inside every cell -> deterministic tie-break
+    std::vector<float> recs((size_t)std::max<int64_t>(nrefs, 1) * 12, 0.0f);
     std::vector<int32_t> cursor(start.begin(), start.end() - 1);
-    for (int64_t f = 0; f < F; ++f)  // ascending f inside every cell -> deterministic closest-hit tie-break
+    for (int64_t f = 0; f < F; ++f)
         for (int iy = ra[f * 4 + 2]; iy <= ra[f * 4 + 3]; ++iy)
-            for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix) refs[cursor[(size_t)iy * nx + ix]++] = (int32_t)f;
+            for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix) {
+                float* r = &recs[(size_t)(cursor[(size_t)imx_cell_index(ix, iy, ntx)]++) * 12];
+                memcpy(r, &tv[(size_t)f * 9], 9 * sizeof(float));
+                const int32_t fid = (int32_t)f;
+                memcpy(r + 9, &fid, 4);
+            }
 
     IMX_REQUIRE(imx_device_count() > 0, "imx_mesh_create: no GPU visible");
     auto m = std::make_unique<imx_mesh>();
-    IMX_HIP(hipMalloc((void**)&m->d_tri_verts, tv.size() * sizeof(float)));
+    IMX_HIP(hipMalloc((void**)&m->d_tri_rec, recs.size() * sizeof(float)));
     IMX_HIP(hipMalloc((void**)&m->d_cell_start, start.size() * sizeof(int32_t)));
-    IMX_HIP(hipMalloc((void**)&m->d_cell_tris, refs.size() * sizeof(int32_t)));
-    IMX_HIP(hipMemcpy(m->d_tri_verts, tv.data(), tv.size() * sizeof(float), hipMemcpyHostToDevice));
+    IMX_HIP(hipMemcpy(m->d_tri_rec, recs.data(), recs.size() * sizeof(float), hipMemcpyHostToDevice));
     IMX_HIP(hipMemcpy(m->d_cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    IMX_HIP(hipMemcpy(m->d_cell_tris, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    m->v.tri_verts = m->d_tri_verts;
+    m->v.tri_rec = m->d_tri_rec;
     m->v.cell_start = m->d_cell_start;
-    m->v.cell_tris = m->d_cell_tris;
-    m->v.nx = (int)nx; m->v.ny = (int)ny;
+    m->v.nx = (int)nx; m->v.ny = (int)ny; m->v.ntx = ntx; m->v.nty = nty;
     m->v.x0 = xmin; m->v.y0 = ymin; m->v.cell = cell_size; m->v.inv_cell = inv_cell;
     m->v.F = F;
     m->num_refs = nrefs;
@@ -105,9 +109,8 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
 
 extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
     if (!m) return;
-    if (m->d_tri_verts) (void)hipFree(m->d_tri_verts);
+    if (m->d_tri_rec) (void)hipFree(m->d_tri_rec);
     if (m->d_cell_start) (void)hipFree(m->d_cell_start);
-    if (m->d_cell_tris) (void)hipFree(m->d_cell_tris);
     delete m;
 }
 

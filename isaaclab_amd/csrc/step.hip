@@ -20,21 +20,69 @@ IMX_DEV int wave_sum_i(int v) {
     return v;
 }
 
-// max over history of the force norm on body b (rewards.py:266, terminations.py:157)
+// Sequential-order sum of f(ids[i]), i = 0..n-1, with the loads of 8 terms issued before the first add: the adds
+// keep torch.sum's left-to-right order for these short rows while the memory latency is paid once per 8 elements.
+template <class F>
+IMX_DEV float sum_ids(const int32_t* __restrict__ ids, int n, F f) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = f(ids[min(i + u, n - 1)]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + u < n) acc += x[u];
+    }
+    return acc;
+}
+template <class F>
+IMX_DEV float sum_range(int n, F f) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = f(min(i + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + u < n) acc += x[u];
+    }
+    return acc;
+}
+template <class F>
+IMX_DEV bool any_ids(const int32_t* __restrict__ ids, int n, F f) {
+    bool acc = false;
+    for (int i = 0; i < n; i += 8) {
+        bool x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = f(ids[min(i + u, n - 1)]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc || x[u];  // duplicates of the last id are harmless for 'any'
+    }
+    return acc;
+}
+
+// max over history of the force norm on body b (rewards.py:266, terminations.py:157); 4 history slots per trip
 IMX_DEV float max_hist_force(const float* __restrict__ F, int64_t e, int H, int B, int b) {
     float m = -__builtin_huge_valf();
-    for (int h = 0; h < H; ++h) {
-        const float* f = F + (((size_t)e * H + h) * B + b) * 3;
-        m = fmaxf(m, norm3(f[0], f[1], f[2]));
+    for (int h0 = 0; h0 < H; h0 += 4) {
+        float nrm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = min(h0 + u, H - 1);
+            const float* f = F + (((size_t)e * H + h) * B + b) * 3;
+            nrm[u] = norm3(f[0], f[1], f[2]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(m, nrm[u]);
     }
     return m;
 }
 
-// scratch layout for k_term_rew (all sizes in 4-byte words, nw = number of waves = ceil(N/64))
-//   [0, nw*KA)               float  per-wave partial sums of episode_sums over reset envs
-//   [.., + nw*NT)            int    per-wave counts of term_dones over reset envs
-//   [.., + nw)               int    per-wave reset counts
-//   [.., + nw*64)            int    per-wave compacted local reset ids
+// scratch layout for k_term_rew (4-byte words, nw = number of 64-env groups = ceil(N/64))
+//   [0, nw*KA)               float  per-group partial sums of episode_sums over reset envs
+//   [.., + nw*NT)            int    per-group counts of term_dones over reset envs
+//   [.., + nw)               int    per-group reset counts
+//   [.., + nw*64)            int    per-group compacted local reset ids
 struct StepScratch {
     float* log_part;
     int* term_part;
@@ -95,28 +143,37 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
 }
 
 // ------------------------------------------------------------------------------------------------- terminations + rewards
+// Block = 64 consecutive envs x 4 waves.  Lane l of every wave owns env 64*blockIdx + l.  Every wave evaluates the
+// (cheap) termination terms, so each knows its envs' reset flags; the reward terms are dealt round-robin to the four
+// waves (4x the loads in flight per env), each wave finishing its own terms completely (value, episodic sum,
+// step_reward, reset-log partial).  The per-term values meet in LDS and wave 0 adds them IN TERM ORDER, so the
+// reward is bit-identical to a single-wave sequential evaluation.
+#define IMX_TR_WAVES 4
 __global__ void __launch_bounds__(256)
 k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float s_val[];  // [nrew][64]
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t grp = blockIdx.x;
+    const int64_t e = grp * 64 + lane;
     const bool live = e < N;
     const int64_t ec = live ? e : N - 1;  // clamp: dead lanes compute on a valid env, never store
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int J = P.J, Bn = P.B, H = P.H, A = P.A;
     const int32_t* __restrict__ W = P.w;
 
     // -- root frame (ArticulationData.root_lin_vel_b / root_ang_vel_b / projected_gravity_b)
-    const float qw = S.root_quat_w[ec * 4 + 0], qx = S.root_quat_w[ec * 4 + 1], qy = S.root_quat_w[ec * 4 + 2],
-                qz = S.root_quat_w[ec * 4 + 3];
+    const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[ec];
+    const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
     const float lwx = S.root_lin_vel_w[ec * 3], lwy = S.root_lin_vel_w[ec * 3 + 1], lwz = S.root_lin_vel_w[ec * 3 + 2];
     const float awx = S.root_ang_vel_w[ec * 3], awy = S.root_ang_vel_w[ec * 3 + 1], awz = S.root_ang_vel_w[ec * 3 + 2];
+    const int64_t ep = Bf.episode_length_buf[ec] + 1;  // manager_based_rl_env.py:200
+    const float cmdx = P.CMD > 0 ? S.command[ec * P.CMD + 0] : 0.0f;
+    const float cmdy = P.CMD > 1 ? S.command[ec * P.CMD + 1] : 0.0f;
+    const float cmdz = P.CMD > 2 ? S.command[ec * P.CMD + 2] : 0.0f;
     float lbx, lby, lbz, abx, aby, abz, pgx, pgy, pgz;
     quat_rotate_inverse(qw, qx, qy, qz, lwx, lwy, lwz, lbx, lby, lbz);
     quat_rotate_inverse(qw, qx, qy, qz, awx, awy, awz, abx, aby, abz);
     quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, pgx, pgy, pgz);
-
-    // -- episode counter (manager_based_rl_env.py:200)
-    const int64_t ep = Bf.episode_length_buf[ec] + 1;
 
     // -- TerminationManager.compute (termination_manager.py:151-174)
     uint32_t term_bits = 0;
@@ -131,28 +188,24 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         switch (op) {
             case IMX_T_TIME_OUT: v = ep >= (int64_t)P.max_ep_len; break;
             case IMX_T_ILLEGAL_CONTACT:
-                for (int i = 0; i < n; ++i) v = v || (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > p0);
+                v = any_ids(ids, n, [&](int b) { return max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0; });
                 break;
             case IMX_T_JOINT_POS_MANUAL_LIMIT:
-                for (int i = 0; i < n; ++i) {
-                    const float q = S.joint_pos[ec * J + ids[i]];
-                    v = v || (q > p1) || (q < p0);
-                }
+                v = any_ids(ids, n, [&](int j) { const float q = S.joint_pos[ec * J + j]; return (q > p1) || (q < p0); });
                 break;
             case IMX_T_BAD_ORIENTATION: v = fabsf(acosf(-pgz)) > p0; break;
             case IMX_T_ROOT_HEIGHT_BELOW_MIN: v = S.root_pos_w[ec * 3 + 2] < p0; break;
             case IMX_T_JOINT_VEL_LIMIT:
-                for (int i = 0; i < n; ++i)
-                    v = v || (fabsf(S.joint_vel[ec * J + ids[i]]) > S.soft_joint_vel_limits[ec * J + ids[i]]);
+                v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > S.soft_joint_vel_limits[ec * J + j]; });
                 break;
             case IMX_T_JOINT_VEL_MANUAL_LIMIT:
-                for (int i = 0; i < n; ++i) v = v || (fabsf(S.joint_vel[ec * J + ids[i]]) > p0);
+                v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > p0; });
                 break;
             case IMX_T_JOINT_EFFORT_LIMIT:  // torch.isclose(computed, applied): |a-b| <= atol + rtol*|b|
-                for (int i = 0; i < n; ++i) {
-                    const float a = S.computed_torque[ec * J + ids[i]], b = S.applied_torque[ec * J + ids[i]];
-                    v = v || (fabsf(a - b) <= 1.0e-8f + 1.0e-5f * fabsf(b));
-                }
+                v = any_ids(ids, n, [&](int j) {
+                    const float a = S.computed_torque[ec * J + j], b = S.applied_torque[ec * J + j];
+                    return fabsf(a - b) <= 1.0e-8f + 1.0e-5f * fabsf(b);
+                });
                 break;
             case IMX_T_TERRAIN_OUT_OF_BOUNDS:
                 v = (fabsf(S.root_pos_w[ec * 3]) > p0) || (fabsf(S.root_pos_w[ec * 3 + 1]) > p1);
@@ -162,29 +215,17 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         }
         if (r[IMX_R_WEIGHT]) truncated = truncated || v; else terminated = terminated || v;
         term_bits |= v ? (1u << k) : 0u;
-        if (live) Bf.term_dones[(size_t)k * N + e] = v ? 1 : 0;
+        if (live && wv == 0) Bf.term_dones[(size_t)k * N + e] = v ? 1 : 0;
     }
     const bool reset = live && (terminated || truncated);
 
-    // -- RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; reward += value; sums += value
+    // -- RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; sums += value; step_reward = value/dt
     const float dt = P.step_dt;
-    float reward = 0.0f;
-    const float cmdx = P.CMD > 0 ? S.command[ec * P.CMD + 0] : 0.0f;
-    const float cmdy = P.CMD > 1 ? S.command[ec * P.CMD + 1] : 0.0f;
-    const float cmdz = P.CMD > 2 ? S.command[ec * P.CMD + 2] : 0.0f;
-    int next_all = 0;  // reward-manager term index cursor: terms skipped for zero weight still own a slot
-    for (int k = 0; k <= P.nrew; ++k) {
+    const bool moving = sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f;  // torch.norm(cmd[:, :2]) > 0.1
+    for (int k = wv; k < P.nrew; k += IMX_TR_WAVES) {
         const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
-        const int idx = (k < P.nrew) ? r[IMX_R_OUT] : P.nrew_all;
-        // slots of skipped terms: episode sum stays as is (0 since reset), but it is part of the reset/log pass
-        for (; next_all < idx; ++next_all) {
-            const float es = live ? Bf.episode_sums[(size_t)next_all * N + e] : 0.0f;
-            const float part = wave_sum(reset ? es : 0.0f);
-            if (lane == 0) sc.log_part[wave * P.nrew_all + next_all] = part;
-            if (reset) Bf.episode_sums[(size_t)next_all * N + e] = 0.0f;
-        }
-        if (k == P.nrew) break;
-        next_all = idx + 1;
+        const int idx = r[IMX_R_OUT];
+        const float es0 = live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f;  // issued early: independent of the term
         const int op = r[IMX_R_OP];
         const int32_t* ids = W + r[IMX_R_IDS_OFF];
         const int n = r[IMX_R_NIDS];
@@ -203,52 +244,47 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
             case IMX_W_FLAT_ORIENTATION_L2: f = pgx * pgx + pgy * pgy; break;
             case IMX_W_BASE_HEIGHT_L2: { const float d = S.root_pos_w[ec * 3 + 2] - p0; f = d * d; } break;
             case IMX_W_JOINT_TORQUES_L2:
-                for (int i = 0; i < n; ++i) { const float x = S.applied_torque[ec * J + ids[i]]; f += x * x; }
+                f = sum_ids(ids, n, [&](int j) { const float x = S.applied_torque[ec * J + j]; return x * x; });
                 break;
-            case IMX_W_JOINT_VEL_L1:
-                for (int i = 0; i < n; ++i) f += fabsf(S.joint_vel[ec * J + ids[i]]);
-                break;
+            case IMX_W_JOINT_VEL_L1: f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]); }); break;
             case IMX_W_JOINT_VEL_L2:
-                for (int i = 0; i < n; ++i) { const float x = S.joint_vel[ec * J + ids[i]]; f += x * x; }
+                f = sum_ids(ids, n, [&](int j) { const float x = S.joint_vel[ec * J + j]; return x * x; });
                 break;
             case IMX_W_JOINT_ACC_L2:
-                for (int i = 0; i < n; ++i) { const float x = S.joint_acc[ec * J + ids[i]]; f += x * x; }
+                f = sum_ids(ids, n, [&](int j) { const float x = S.joint_acc[ec * J + j]; return x * x; });
                 break;
             case IMX_W_JOINT_DEVIATION_L1:
-                for (int i = 0; i < n; ++i)
-                    f += fabsf(S.joint_pos[ec * J + ids[i]] - S.default_joint_pos[ec * J + ids[i]]);
+                f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_pos[ec * J + j] - S.default_joint_pos[ec * J + j]); });
                 break;
             case IMX_W_JOINT_POS_LIMITS:
-                for (int i = 0; i < n; ++i) {
-                    const float q = S.joint_pos[ec * J + ids[i]];
-                    const float lo = S.soft_joint_pos_limits[(ec * J + ids[i]) * 2],
-                                hi = S.soft_joint_pos_limits[(ec * J + ids[i]) * 2 + 1];
-                    float o = -fminf(q - lo, 0.0f);
-                    o += fmaxf(q - hi, 0.0f);
-                    f += o;
-                }
+                f = sum_ids(ids, n, [&](int j) {
+                    const float q = S.joint_pos[ec * J + j];
+                    const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[ec * J + j];
+                    float o = -fminf(q - lim.x, 0.0f);
+                    o += fmaxf(q - lim.y, 0.0f);
+                    return o;
+                });
                 break;
             case IMX_W_JOINT_VEL_LIMITS:
-                for (int i = 0; i < n; ++i) {
-                    const float o = fabsf(S.joint_vel[ec * J + ids[i]]) - S.soft_joint_vel_limits[ec * J + ids[i]] * p0;
-                    f += fminf(fmaxf(o, 0.0f), 1.0f);
-                }
+                f = sum_ids(ids, n, [&](int j) {
+                    const float o = fabsf(S.joint_vel[ec * J + j]) - S.soft_joint_vel_limits[ec * J + j] * p0;
+                    return fminf(fmaxf(o, 0.0f), 1.0f);
+                });
                 break;
             case IMX_W_APPLIED_TORQUE_LIMITS:
-                for (int i = 0; i < n; ++i)
-                    f += fabsf(S.applied_torque[ec * J + ids[i]] - S.computed_torque[ec * J + ids[i]]);
+                f = sum_ids(ids, n, [&](int j) { return fabsf(S.applied_torque[ec * J + j] - S.computed_torque[ec * J + j]); });
                 break;
             case IMX_W_ACTION_RATE_L2:
-                for (int i = 0; i < A; ++i) { const float d = Bf.action[ec * A + i] - Bf.prev_action[ec * A + i]; f += d * d; }
+                f = sum_range(A, [&](int i) { const float d = Bf.action[ec * A + i] - Bf.prev_action[ec * A + i]; return d * d; });
                 break;
             case IMX_W_ACTION_L2:
-                for (int i = 0; i < A; ++i) { const float a = Bf.action[ec * A + i]; f += a * a; }
+                f = sum_range(A, [&](int i) { const float a = Bf.action[ec * A + i]; return a * a; });
                 break;
             case IMX_W_UNDESIRED_CONTACTS:
-                for (int i = 0; i < n; ++i) f += (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > p0) ? 1.0f : 0.0f;
+                f = sum_ids(ids, n, [&](int b) { return (max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0) ? 1.0f : 0.0f; });
                 break;
             case IMX_W_CONTACT_FORCES:
-                for (int i = 0; i < n; ++i) f += fmaxf(max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) - p0, 0.0f);
+                f = sum_ids(ids, n, [&](int b) { return fmaxf(max_hist_force(S.net_forces_w_history, ec, H, Bn, b) - p0, 0.0f); });
                 break;
             case IMX_W_TRACK_LIN_VEL_XY_EXP: {
                 const float ex = cmdx - lbx, ey = cmdy - lby;
@@ -258,12 +294,12 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
             case IMX_W_FEET_AIR_TIME: {
                 // first_contact = (cct > 0) * (cct < dt + abs_tol); p1 = float32(step_dt + 1e-8)
                 const float p1 = f_of(r[IMX_R_P1]);
-                for (int i = 0; i < n; ++i) {
-                    const float cct = S.current_contact_time[ec * Bn + ids[i]];
+                f = sum_ids(ids, n, [&](int b) {
+                    const float cct = S.current_contact_time[ec * Bn + b];
                     const float fc = (cct > 0.0f && cct < p1) ? 1.0f : 0.0f;
-                    f += (S.last_air_time[ec * Bn + ids[i]] - p0) * fc;
-                }
-                f *= (sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f) ? 1.0f : 0.0f;
+                    return (S.last_air_time[ec * Bn + b] - p0) * fc;
+                });
+                f *= moving ? 1.0f : 0.0f;
             } break;
             case IMX_W_FEET_AIR_TIME_POSITIVE_BIPED: {
                 int n_contact = 0;
@@ -275,7 +311,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
                     mn = fminf(mn, (n_contact == 1) ? in_mode : 0.0f);
                 }
                 f = fminf(mn, p0);
-                f *= (sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f) ? 1.0f : 0.0f;
+                f *= moving ? 1.0f : 0.0f;
             } break;
             case IMX_W_FEET_SLIDE: {
                 const int32_t* ids2 = W + r[IMX_R_IDS2_OFF];
@@ -294,51 +330,63 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
             } break;
             case IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP: { const float ez = cmdz - awz; f = expf(-(ez * ez) / p0); } break;
             case IMX_W_JOINT_POS_TARGET_L2:
-                for (int i = 0; i < n; ++i) { const float d = wrap_to_pi(S.joint_pos[ec * J + ids[i]]) - p0; f += d * d; }
+                f = sum_ids(ids, n, [&](int j) { const float d = wrap_to_pi(S.joint_pos[ec * J + j]) - p0; return d * d; });
                 break;
             case IMX_W_EXTERNAL: f = S.ext_reward[ec * (int64_t)W[IMX_H_NEXT_REW] + r[IMX_R_AUX0]]; break;
             default: break;
         }
         const float value = f * f_of(r[IMX_R_WEIGHT]) * dt;
-        reward += value;
-        const float es = (live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f) + value;
+        s_val[k * 64 + lane] = value;
+        const float es = es0 + value;
         if (live) {
             Bf.step_reward[(size_t)e * P.nrew_all + idx] = value / dt;
             Bf.episode_sums[(size_t)idx * N + e] = reset ? 0.0f : es;
         }
         // RewardManager.reset log (reward_manager.py:115-121): mean over reset envs of the episodic sum
         const float part = wave_sum(reset ? es : 0.0f);
-        if (lane == 0) sc.log_part[wave * P.nrew_all + idx] = part;
+        if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
+    }
+    // slots of zero-weight terms (skipped by compute, reward_manager.py:145) still take part in the reset/log pass
+    for (int q = wv; q < P.nskip; q += IMX_TR_WAVES) {
+        const int idx = W[P.skip_off + q];
+        const float es = live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f;
+        const float part = wave_sum(reset ? es : 0.0f);
+        if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
+        if (reset) Bf.episode_sums[(size_t)idx * N + e] = 0.0f;
+    }
+    __syncthreads();
+
+    if (wv == 0) {
+        float reward = 0.0f;
+        for (int k = 0; k < P.nrew; ++k) reward += s_val[k * 64 + lane];  // term order
+        // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
+        if (live) {
+            Bf.reward_buf[e] = reward;
+            Bf.terminated[e] = terminated ? 1 : 0;
+            Bf.truncated[e] = truncated ? 1 : 0;
+            Bf.reset_buf[e] = reset ? 1 : 0;
+            Bf.episode_length_buf[e] = reset ? 0 : ep;
+            if (reset)
+                for (int i = 0; i < A; ++i) {  // ActionManager.reset (action_manager.py:306-316)
+                    Bf.action[e * A + i] = 0.0f;
+                    Bf.prev_action[e * A + i] = 0.0f;
+                }
+        }
+        // TerminationManager.reset log (termination_manager.py:142-144): count_nonzero(term_dones[reset ids])
+        for (int k = 0; k < P.nterm; ++k) {
+            const int c = wave_sum_i((reset && ((term_bits >> k) & 1u)) ? 1 : 0);
+            if (lane == 0) sc.term_part[grp * P.nterm + k] = c;
+        }
+        // ordered compaction inside the group: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
+        const unsigned long long ballot = __ballot(reset);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (reset) sc.ids_local[grp * 64 + before] = lane;
+        if (lane == 0) sc.wave_cnt[grp] = __popcll(ballot);
     }
 
-    // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
-    if (live) {
-        Bf.reward_buf[e] = reward;
-        Bf.terminated[e] = terminated ? 1 : 0;
-        Bf.truncated[e] = truncated ? 1 : 0;
-        Bf.reset_buf[e] = reset ? 1 : 0;
-        Bf.episode_length_buf[e] = reset ? 0 : ep;
-        if (reset)
-            for (int i = 0; i < A; ++i) {  // ActionManager.reset (action_manager.py:306-316)
-                Bf.action[e * A + i] = 0.0f;
-                Bf.prev_action[e * A + i] = 0.0f;
-            }
-    }
-    // TerminationManager.reset log (termination_manager.py:142-144): count_nonzero(term_dones[reset ids])
-    for (int k = 0; k < P.nterm; ++k) {
-        const int c = wave_sum_i((reset && ((term_bits >> k) & 1u)) ? 1 : 0);
-        if (lane == 0) sc.term_part[wave * P.nterm + k] = c;
-    }
-    // ordered compaction inside the wave: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
-    const unsigned long long ballot = __ballot(reset);
-    const int before = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (reset) sc.ids_local[wave * 64 + before] = (int)(e & 63);
-    if (lane == 0) sc.wave_cnt[wave] = __popcll(ballot);
-
-    // -- last block finishes: ordered concatenation of the per-wave id lists + log reductions (deterministic order)
+    // -- last block finishes: ordered concatenation of the per-group id lists + log reductions (deterministic order)
     __shared__ int s_last;
-    __shared__ float s_red[256];
-    __shared__ int s_scan[256];
+    __shared__ int s_scan[IMX_TR_WAVES];
     __threadfence();  // release this block's partials (agent scope)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -352,23 +400,29 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     const int nw = (int)((N + 63) / 64);
     const int T = blockDim.x;
     const int t = threadIdx.x;
-    // exclusive scan of wave counts: thread t owns waves [t*chunk, (t+1)*chunk)
+    // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + 4 wave totals
     const int chunk = (nw + T - 1) / T;
     int local = 0;
     for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) local += __builtin_nontemporal_load(&sc.wave_cnt[w]);
-    s_scan[t] = local;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int i = 0; i < T; ++i) { const int c = s_scan[i]; s_scan[i] = run; run += c; }
-        Bf.counters[0] = run;  // number of reset envs
-        Bf.counters[1] = 0;    // re-arm the ticket
-        Bf.counters[2] += 1;   // step counter (keys the observation-noise stream)
-        s_last = run;
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
     }
+    if (lane == 63) s_scan[wv] = incl;
     __syncthreads();
-    const int total = s_last;
-    int off = s_scan[t];
+    int wave_base = 0, total = 0;
+    for (int w = 0; w < IMX_TR_WAVES; ++w) {
+        if (w < wv) wave_base += s_scan[w];
+        total += s_scan[w];
+    }
+    if (t == 0) {
+        Bf.counters[0] = total;  // number of reset envs
+        Bf.counters[1] = 0;      // re-arm the ticket
+        Bf.counters[2] += 1;     // step counter (keys the observation-noise stream)
+    }
+    int off = wave_base + incl - local;
     for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
         const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
         for (int j = 0; j < c; ++j)
@@ -376,131 +430,149 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         off += c;
     }
     if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
-        for (int k = 0; k < P.nrew_all; ++k) {
-            float s = 0.0f;
-            for (int w = t; w < nw; w += T) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
-            s_red[t] = s;
-            __syncthreads();
-            for (int o = T >> 1; o > 0; o >>= 1) {
-                if (t < o) s_red[t] += s_red[t + o];
-                __syncthreads();
+        // one wave per log entry: lanes stride over the groups, fixed-shape shuffle tree -> deterministic
+        const int nlog = P.nrew_all + P.nterm;
+        for (int k = wv; k < nlog; k += IMX_TR_WAVES) {
+            if (k < P.nrew_all) {
+                float s = 0.0f;
+                for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
+                s = wave_sum(s);
+                if (lane == 0) Bf.log_out[k] = s / (float)total / P.max_ep_len_s;
+            } else {
+                const int kt = k - P.nrew_all;
+                int s = 0;
+                for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.term_part[(size_t)w * P.nterm + kt]);
+                s = wave_sum_i(s);
+                if (lane == 0) Bf.log_out[k] = (float)s;
             }
-            if (t == 0) Bf.log_out[k] = s_red[0] / (float)total / P.max_ep_len_s;
-            __syncthreads();
         }
-        for (int k = 0; k < P.nterm; ++k) {
-            int s = 0;
-            for (int w = t; w < nw; w += T) s += __builtin_nontemporal_load(&sc.term_part[(size_t)w * P.nterm + k]);
-            s_scan[t] = s;
-            __syncthreads();
-            for (int o = T >> 1; o > 0; o >>= 1) {
-                if (t < o) s_scan[t] += s_scan[t + o];
-                __syncthreads();
-            }
-            if (t == 0) Bf.log_out[P.nrew_all + k] = (float)s_scan[0];
-            __syncthreads();
-        }
-        if (t == 0) Bf.log_out[P.nrew_all + P.nterm] = (float)total;
+        if (t == 0) Bf.log_out[nlog] = (float)total;
     }
 }
 
 // ------------------------------------------------------------------------------------------------- observations
-// One block = EB consecutive envs.  Phase 1 (EB lanes): per-env derived state into LDS (root-frame vectors, yaw
-// quaternion of the height-scanner).  Phase 2: one output element per lane, ray columns first (heavy work is
-// contiguous in the wave), results stored straight to obs[e*D + c] -- consecutive lanes, consecutive addresses.
-#define IMX_ENV_S 24  // floats of per-env LDS state
-template <int EB>
-__global__ void __launch_bounds__(256)
+// One WAVE = one environment (4 envs per 256-thread block).  Every lane first derives the env's root-frame vectors
+// and scanner yaw from the same 13 root-state floats (wave-uniform loads: one transaction, no LDS, no barrier);
+// then lane l produces the output columns xcol[l], xcol[l+64], ... (ray columns first) and stores obs[e*D + c]:
+// within a term the 64 lanes of a wave write 64 consecutive floats.
+//
+// xcol is the per-column expansion of the observation records built once by imx_plan_create (16 words per column:
+// everything a lane needs arrives with four 16-byte loads instead of a chain order -> column -> record -> id table).
+// Height-scanner rays (yaw-only frame, vertical direction) take a fast path that keeps up to four rays of a lane
+// in flight: cell-table loads of all four, then the 48-byte triangle records of all four, then the Woop tests.
+#define IMX_OBS_ENVS_PER_BLOCK 4
+#define IMX_XCOL_WORDS 16
+enum { XC_COL = 0, XC_OP, XC_J, XC_FLAGS, XC_P0, XC_NLO, XC_NHI, XC_CLO, XC_CHI, XC_SCALE, XC_AUX, XC_RX, XC_RY, XC_RZ };
+
+struct XCol {
+    int4 a, b, c, d;
+};
+IMX_DEV XCol load_xcol(const int32_t* __restrict__ W, int off, int i) {
+    const int4* p = reinterpret_cast<const int4*>(W + off) + (size_t)i * 4;
+    XCol x;
+    x.a = p[0]; x.b = p[1]; x.c = p[2]; x.d = p[3];
+    return x;
+}
+
+IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restrict__ noise_u, uint64_t seed, uint32_t step,
+                       int64_t e, int D) {
+    const int flags = x.a.w;
+    if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
+        const int c = x.a.x;
+        const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
+        const float lo = f_of(x.b.y), hi = f_of(x.b.z);
+        const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
+        v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
+    }
+    if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, f_of(x.b.w)), f_of(x.c.x));
+    if (flags & IMX_F_SCALE) v = v * f_of(x.c.y);
+    return v;
+}
+
+// One single-wave BLOCK = 64 output columns of one environment (ray columns first in xcol).  The wave derives the
+// env's root-frame vectors and the scanner yaw (uniform loads, ~300 VALU ops), parks them in LDS (a register
+// spill area: no barrier, the block is one wave), and every lane then is an independent, register-light stream: xcol (four 16-byte loads) -> value -> noise/clip/scale -> obs[e*D + c].
+// Occupancy, not instruction-level parallelism, hides the ray-cast's dependent loads (cell table -> triangle
+// records): ~50 VGPRs, 16 K waves for 4096 envs.  Consecutive lanes write consecutive floats of one obs row.
+#define IMX_ES_WORDS 20
+template <bool GENERAL_RAYS>
+__global__ void __launch_bounds__(64)
 k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ noise_u,
       uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
-    __shared__ float es[EB][IMX_ENV_S];
-    const int64_t e0 = (int64_t)blockIdx.x * EB;
+    __shared__ float es[IMX_ES_WORDS];
+    const int nchunk = (P.D + 63) >> 6;  // 64-lane blocks per env
+    const int64_t e = blockIdx.x / nchunk;
+    const int chunk = (int)(blockIdx.x - e * nchunk);
     const int32_t* __restrict__ W = P.w;
-    if (threadIdx.x < EB) {
-        const int64_t e = min(e0 + threadIdx.x, N - 1);
-        float* s = es[threadIdx.x];
-        const float qw = S.root_quat_w[e * 4], qx = S.root_quat_w[e * 4 + 1], qy = S.root_quat_w[e * 4 + 2],
-                    qz = S.root_quat_w[e * 4 + 3];
-        quat_rotate_inverse(qw, qx, qy, qz, S.root_lin_vel_w[e * 3], S.root_lin_vel_w[e * 3 + 1],
-                            S.root_lin_vel_w[e * 3 + 2], s[0], s[1], s[2]);
-        quat_rotate_inverse(qw, qx, qy, qz, S.root_ang_vel_w[e * 3], S.root_ang_vel_w[e * 3 + 1],
-                            S.root_ang_vel_w[e * 3 + 2], s[3], s[4], s[5]);
-        quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, s[6], s[7], s[8]);
-        s[9] = S.root_pos_w[e * 3]; s[10] = S.root_pos_w[e * 3 + 1]; s[11] = S.root_pos_w[e * 3 + 2];
-        s[12] = qw; s[13] = qx; s[14] = qy; s[15] = qz;
-        float yw = 1.0f, yz = 0.0f;
-        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, yw, yz);
-        s[16] = yw; s[17] = yz;
-    }
-    __syncthreads();
-    const uint32_t step = (uint32_t)Bf.counters[2];
     const int D = P.D, J = P.J;
-    const int total = EB * D;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        // work order: all ray columns of all EB envs first, then the rest
-        int el, c;
-        const int nray = EB * P.n_ray_cols;
-        if (i < nray) {
-            el = i / P.n_ray_cols;
-            c = W[P.order_off + (i - el * P.n_ray_cols)];
-        } else {
-            const int rem = i - nray, np = D - P.n_ray_cols;
-            el = rem / np;
-            c = W[P.order_off + P.n_ray_cols + (rem - el * np)];
+    {  // all lanes redundantly (uniform addresses: one transaction each); the block is ONE wave, so the LDS hand-off
+       // below needs no barrier
+        const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[e];
+        float v[IMX_ES_WORDS];
+        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_lin_vel_w[e * 3], S.root_lin_vel_w[e * 3 + 1],
+                            S.root_lin_vel_w[e * 3 + 2], v[0], v[1], v[2]);
+        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_ang_vel_w[e * 3], S.root_ang_vel_w[e * 3 + 1],
+                            S.root_ang_vel_w[e * 3 + 2], v[3], v[4], v[5]);
+        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, P.gx, P.gy, P.gz, v[6], v[7], v[8]);
+        v[9] = S.root_pos_w[e * 3]; v[10] = S.root_pos_w[e * 3 + 1]; v[11] = S.root_pos_w[e * 3 + 2];
+        v[12] = q4.x; v[13] = q4.y; v[14] = q4.z; v[15] = q4.w;
+        v[16] = 1.0f; v[17] = 0.0f;
+        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(q4.x, q4.y, q4.z, q4.w, v[16], v[17]);
+        if (threadIdx.x < 18) {
+            float x = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) x = (threadIdx.x == k) ? v[k] : x;
+            es[threadIdx.x] = x;
         }
-        const int64_t e = e0 + el;
-        if (e >= N) continue;
-        const float* s = es[el];
-        const int cr = W[P.col_off + c];
-        const int32_t* r = W + P.obs_off + (cr >> 16) * IMX_REC_WORDS;
-        const int j = cr & 0xFFFF;
-        const int op = r[IMX_R_OP];
-        const int flags = r[IMX_R_FLAGS];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t step = (uint32_t)Bf.counters[2];
+    const float pz = es[11];
+    const int i = chunk * 64 + (int)threadIdx.x;
+    if (i < D) {
+        const XCol x = load_xcol(W, P.xcol_off, i);
+        const int c = x.a.x, op = x.a.y, j = x.a.z, flags = x.a.w, aux = x.c.z;
         float v = 0.0f;
         switch (op) {
-            case IMX_O_BASE_POS_Z: v = s[11]; break;
-            case IMX_O_BASE_LIN_VEL: v = s[0 + j]; break;
-            case IMX_O_BASE_ANG_VEL: v = s[3 + j]; break;
-            case IMX_O_PROJECTED_GRAVITY: v = s[6 + j]; break;
-            case IMX_O_ROOT_POS_W: v = s[9 + j] - S.env_origins[e * 3 + j]; break;
-            case IMX_O_ROOT_QUAT_W: v = (flags & IMX_F_QUAT_UNIQUE) && s[12] < 0.0f ? -s[12 + j] : s[12 + j]; break;
+            case IMX_O_BASE_POS_Z: v = pz; break;
+            case IMX_O_BASE_LIN_VEL: v = es[0 + j]; break;
+            case IMX_O_BASE_ANG_VEL: v = es[3 + j]; break;
+            case IMX_O_PROJECTED_GRAVITY: v = es[6 + j]; break;
+            case IMX_O_ROOT_POS_W: v = es[9 + j] - S.env_origins[e * 3 + j]; break;
+            case IMX_O_ROOT_QUAT_W: v = ((flags & IMX_F_QUAT_UNIQUE) && es[12] < 0.0f) ? -es[12 + j] : es[12 + j]; break;
             case IMX_O_ROOT_LIN_VEL_W: v = S.root_lin_vel_w[e * 3 + j]; break;
             case IMX_O_ROOT_ANG_VEL_W: v = S.root_ang_vel_w[e * 3 + j]; break;
-            case IMX_O_JOINT_POS: v = S.joint_pos[e * J + W[r[IMX_R_IDS_OFF] + j]]; break;
-            case IMX_O_JOINT_POS_REL: {
-                const int jid = W[r[IMX_R_IDS_OFF] + j];
-                v = S.joint_pos[e * J + jid] - S.default_joint_pos[e * J + jid];
-            } break;
+            case IMX_O_JOINT_POS: v = S.joint_pos[e * J + aux]; break;
+            case IMX_O_JOINT_POS_REL: v = S.joint_pos[e * J + aux] - S.default_joint_pos[e * J + aux]; break;
             case IMX_O_JOINT_POS_LIMIT_NORMALIZED: {  // scale_transform (utils/math.py:22-40)
-                const int jid = W[r[IMX_R_IDS_OFF] + j];
-                const float lo = S.soft_joint_pos_limits[(e * J + jid) * 2], hi = S.soft_joint_pos_limits[(e * J + jid) * 2 + 1];
-                const float offset = (lo + hi) * 0.5f;
-                v = 2.0f * (S.joint_pos[e * J + jid] - offset) / (hi - lo);
+                const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * J + aux];
+                const float offset = (lim.x + lim.y) * 0.5f;
+                v = 2.0f * (S.joint_pos[e * J + aux] - offset) / (lim.y - lim.x);
             } break;
-            case IMX_O_JOINT_VEL: v = S.joint_vel[e * J + W[r[IMX_R_IDS_OFF] + j]]; break;
-            case IMX_O_JOINT_VEL_REL: {
-                const int jid = W[r[IMX_R_IDS_OFF] + j];
-                v = S.joint_vel[e * J + jid] - S.default_joint_vel[e * J + jid];
-            } break;
+            case IMX_O_JOINT_VEL: v = S.joint_vel[e * J + aux]; break;
+            case IMX_O_JOINT_VEL_REL: v = S.joint_vel[e * J + aux] - S.default_joint_vel[e * J + aux]; break;
             case IMX_O_LAST_ACTION: v = Bf.action[e * P.A + j]; break;
             case IMX_O_GENERATED_COMMANDS: v = S.command[e * P.CMD + j]; break;
-            case IMX_O_EXTERNAL: v = S.ext_obs[e * (int64_t)W[IMX_H_NEXT_OBS] + r[IMX_R_AUX0] + j]; break;
+            case IMX_O_EXTERNAL: v = S.ext_obs[e * (int64_t)W[IMX_H_NEXT_OBS] + aux + j]; break;
             case IMX_O_HEIGHT_SCAN: {
                 // RayCaster._update_buffers_impl (ray_caster.py:242-260) + height_scan (observations.py:165-173)
-                const float lx = f_of(W[P.ray_off + 3 * j]), ly = f_of(W[P.ray_off + 3 * j + 1]),
-                            lz = f_of(W[P.ray_off + 3 * j + 2]);
+                const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
                 float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
                 if (P.ray_yaw_only) {
-                    quat_apply_yaw_only(s[16], s[17], lx, ly, lz, sx, sy, sz);
-                } else {
-                    quat_apply(s[12], s[13], s[14], s[15], lx, ly, lz, sx, sy, sz);
-                    quat_apply(s[12], s[13], s[14], s[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
+                    quat_apply_yaw_only(es[16], es[17], lx, ly, lz, sx, sy, sz);
+                } else {  // ray_caster.py:249-252: full orientation for starts and directions
+                    quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
+                    quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
                 }
-                sx += s[9]; sy += s[10]; sz += s[11];
+                sx += es[9]; sy += es[10]; sz += pz;
                 float t;
                 int32_t face;
                 float hx, hy, hz;
-                if (cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)) {
+                const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
+                                              : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
+                if (hit) {
                     hx = sx + t * dx; hy = sy + t * dy; hz = sz + t * dz;  // kernels.py:69
                 } else {
                     hx = hy = hz = __builtin_huge_valf();  // ops.py:70
@@ -509,20 +581,11 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
                     float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
                     o[0] = hx; o[1] = hy; o[2] = hz;
                 }
-                v = s[11] - hz - f_of(r[IMX_R_P0]);
+                v = pz - hz - f_of(x.b.x);
             } break;
             default: break;
         }
-        // post-processing order: noise -> clip -> scale (observation_manager.py:313-318)
-        if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
-            const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
-            const float lo = f_of(r[IMX_R_NOISE_LO]), hi = f_of(r[IMX_R_NOISE_HI]);
-            const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
-            v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
-        }
-        if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, f_of(r[IMX_R_CLIP_LO])), f_of(r[IMX_R_CLIP_HI]));
-        if (flags & IMX_F_SCALE) v = v * f_of(r[IMX_R_SCALE]);
-        Bf.obs[e * D + c] = v;
+        Bf.obs[e * D + c] = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
     }
 }
 
@@ -634,10 +697,11 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
         }
     }
     if (plan->CMD > 0 && !st->command) IMX_FAIL("command tensor missing");
-    const int bs = (N <= 16384) ? 64 : 256;
-    const unsigned grid = (unsigned)((N + bs - 1) / bs);
+    const unsigned grid = (unsigned)((N + 63) / 64);  // one block (4 waves) per 64 envs
     StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
-    hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(bs), 0, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, sc);
+    const size_t lds = (size_t)(plan->nrew > 0 ? plan->nrew : 1) * 64 * sizeof(float);
+    hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
+                       *bf, sc);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -670,10 +734,16 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     MeshView mv{};
     if (mesh) mv = mesh->v;
-    constexpr int EB = 8;
-    const unsigned grid = (unsigned)((N + EB - 1) / EB);
-    hipLaunchKernelGGL(k_obs<EB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, mv,
-                       noise_u_d, seed, enable_corruption, ray_hits_out_d);
+    const unsigned nchunk = (unsigned)((plan->D + 63) / 64);  // one-wave blocks: (env, 64 columns)
+    const PlanView pv = imx_plan_view(plan);
+    // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
+    const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
+    if (vertical)
+        hipLaunchKernelGGL(k_obs<false>, dim3((unsigned)N * nchunk), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, noise_u_d,
+                           seed, enable_corruption, ray_hits_out_d);
+    else
+        hipLaunchKernelGGL(k_obs<true>, dim3((unsigned)N * nchunk), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, noise_u_d,
+                           seed, enable_corruption, ray_hits_out_d);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -690,8 +760,8 @@ extern "C" int imx_root_frame(int64_t N, const float* q, const float* lv, const 
 
 extern "C" int imx_raycast(const imx_mesh_t* mesh, const float* starts, const float* dirs, int64_t n, float max_dist,
                            float* hits, float* dist, int32_t* faces, imx_stream_t stream) {
-    IMX_REQUIRE(mesh && starts && dirs && hits, "imx_raycast: null argument");
     if (n == 0) return 0;
+    IMX_REQUIRE(mesh && starts && dirs && hits, "imx_raycast: null argument");
     IMX_REQUIRE(n > 0, "imx_raycast: negative ray count");
     hipLaunchKernelGGL(k_raycast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mesh->v, starts,
                        dirs, n, max_dist, hits, dist, faces);

@@ -64,7 +64,9 @@ class ActorCritic(nn.Module):
 
     def act(self, observations, **kwargs):
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # == distribution.sample(); torch.normal(mean, std_tensor) validates std on the host (a stream sync that
+        # cannot be captured in a hipGraph), randn_like does not
+        return self.distribution.mean + self.distribution.stddev * torch.randn_like(self.distribution.mean)
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .actor_critic import ActorCritic
+from .gemm_tuning import enable_recorded_gemm_tuning
 from .ppo import PPO
 
 
@@ -27,6 +28,8 @@ class OnPolicyRunner:
         self.device = torch.device(device)
         self.env = env
         self._configure_multi_gpu()
+        if self.device.type == "cuda":
+            enable_recorded_gemm_tuning()
         obs, extras = self.env.get_observations()
         num_obs = obs.shape[1]
         num_privileged_obs = extras["observations"]["critic"].shape[1] if "critic" in extras["observations"] else num_obs

@@ -32,7 +32,7 @@ def test_raycast_matches_brute_force_oracles():
     v, t, ext = make_rough_terrain(2, 3, tile=4.0, border=2.0, seed=21)
     rng = np.random.default_rng(0)
     R = 20000
-    starts = np.stack([rng.uniform(-7, 7, R), rng.uniform(-9, 9, R), rng.uniform(19, 21, R)], 1).astype(np.float32)
+    starts = np.stack([rng.uniform(-6.2, 6.2, R), rng.uniform(-8.2, 8.2, R), rng.uniform(19, 21, R)], 1).astype(np.float32)
     # lattice-aligned rays too: exactly on vertices / edges of the height field
     starts[:2000, 0] = np.round(starts[:2000, 0] * 10) / 10
     starts[1000:3000, 1] = np.round(starts[1000:3000, 1] * 10) / 10
