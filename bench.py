@@ -36,16 +36,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def obs_kernel_bytes_per_env(plan) -> float:
-    """Algorithmic HBM bytes of k_obs per env-step (DESIGN.md section 'roofline'): state reads + unique terrain
-    data under the scanner footprint + the obs row written."""
+    """ALGORITHMIC HBM bytes of k_obs per env-step, SURVEY.md section 8(d) figures:
+    obs-side manager reads (root 13 f, joint pos/vel + defaults 4J f, last action A f, command 3 f) + the obs row
+    written (D f) + for the fused z-only ray-cast the unique terrain data under the 1.6 x 1.0 m footprint
+    (18 x 12 vertices x 12 B = 2.6 KB; the 187 x 4 B hit-z write of the un-fused form is the obs row itself)."""
     J, A, D, R = plan.num_joints, plan.action_dim, plan.obs_dim, plan.num_rays
-    reads = (13 + 4 * J + A + 3) * 4  # root state, joint pos/vel + defaults, last action, command
-    mesh = 0.0
-    if R:
-        # unique triangles under a 1.6 x 1.0 m footprint on a 0.1 m height field: (16+1)x(10+1) cells x 2 triangles
-        # x 36 B packed corners + cell table 17x11 x 4 B + triangle ids 17x11x2 x 4 B
-        cells = 17 * 11
-        mesh = cells * 2 * 36 + cells * 4 + cells * 2 * 4
+    reads = (13 + 4 * J + A + 3) * 4
+    mesh = 18 * 12 * 12 if R else 0
     writes = D * 4
     return float(reads + mesh + writes)
 
@@ -138,19 +135,35 @@ def cpu_baseline(task, num_envs, T, budget_s=12.0):
         feed.advance()
         env.post_physics_step(None)
 
-    for _ in range(3):
-        step()
-    steps = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    def rollout():
         for _ in range(T):
             step()
         compute_returns(rew, val, dones, last, 0.99, 0.95, True)
+
+    # eager torch on small tensors is dispatch-bound: more threads is not faster.  Probe a few thread counts on a
+    # short sample, then spend the budget on the best one (the GPU box gives 16 cores to a 1-GPU job).
+    ncpu = os.cpu_count() or 1
+    cands = sorted({1, 4, 8, min(16, ncpu)})
+    probe = {}
+    for nt in cands:
+        torch.set_num_threads(nt)
+        rollout()
+        t0 = time.perf_counter()
+        rollout()
+        probe[nt] = time.perf_counter() - t0
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        rollout()
         steps += T
     dt = time.perf_counter() - t0
-    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    probe_s = ", ".join(f"{k} thr: {num_envs * T / v:.0f}/s" for k, v in probe.items())
+    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"{steps} env-steps of {num_envs} envs ({steps // T} rollouts incl. GAE, obs noise on, "
-                      f"height-scan hits supplied, no policy), {dt:.1f} s, torch {torch.__version__} CPU"}
+                      f"height-scan hits supplied, no policy), {dt:.1f} s, torch {torch.__version__} CPU, "
+                      f"{ncpu} host cores visible; probe {probe_s}"}
 
 
 def main():
@@ -242,9 +255,13 @@ def main():
         achieved = bytes_launch / k_s / 1e9
         out["env_step_path"] = {"value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
                                 "what": "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
-        out["roofline"] = {"bound": "hbm", "kernel": "k_obs<8> (observations + fused height-scanner ray-cast)",
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # PMC passes of tools/pmc_obs.py (same config)
+        if os.path.exists(tf) and args.num_envs == 4096 and args.task == TASK:
+            traffic = json.load(open(tf)).get("k_obs_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": "k_obs<false> (observation assembly + fused height-scanner ray-cast)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
+                           "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
         out["ppo"] = {k: round(v, 6) for k, v in stats.items()}
         out["ppo"]["learning_rate"] = runner.alg.learning_rate
         if world == 1 and not args.no_cpu_baseline:

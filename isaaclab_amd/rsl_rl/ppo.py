@@ -90,6 +90,20 @@ class FlatParams:
         self.grad.zero_()
 
 
+def allreduce_mean_(bucket_grad: torch.Tensor, world_size: int) -> None:
+    """Mean of the flat gradient bucket (+ trailing KL slot) over ranks with ONE collective (RCCL on GPUs)."""
+    dist.all_reduce(bucket_grad, op=dist.ReduceOp.SUM)
+    bucket_grad.div_(world_size)
+
+
+def adaptive_lr_(lr: torch.Tensor, kl: torch.Tensor, desired_kl: float) -> None:
+    """rsl_rl PPO.update 'adaptive' schedule, evaluated on the device (no host sync, identical on every rank
+    because ``kl`` is the all-reduced value): lr /= 1.5 if kl > 2*desired; lr *= 1.5 if 0 < kl < desired/2."""
+    up = torch.clamp(lr * 1.5, max=1e-2)
+    down = torch.clamp(lr / 1.5, min=1e-5)
+    lr.copy_(torch.where(kl > desired_kl * 2.0, down, torch.where((kl < desired_kl / 2.0) & (kl > 0.0), up, lr)))
+
+
 class PPO:
     def __init__(self, policy, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
@@ -158,8 +172,7 @@ class PPO:
 
     def reduce_parameters(self):
         """Mean of the flat gradient bucket (+ KL slot) over ranks: ONE all-reduce."""
-        dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM)
-        self.bucket.grad.div_(self.gpu_world_size)
+        allreduce_mean_(self.bucket.grad, self.gpu_world_size)
 
     # ---- update ----------------------------------------------------------------------------------------------------
     def update(self):
@@ -185,12 +198,7 @@ class PPO:
             if self.is_multi_gpu:
                 self.reduce_parameters()
             if self.desired_kl is not None and self.schedule == "adaptive":
-                kl = b.grad[-1]
-                lr = self._lr
-                up = torch.clamp(lr * 1.5, max=1e-2)
-                down = torch.clamp(lr / 1.5, min=1e-5)
-                self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down,
-                                           torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
+                adaptive_lr_(self._lr, b.grad[-1], self.desired_kl)
             g = b.grad[:b.numel]
             norm = torch.linalg.vector_norm(g).reshape(1) if self.max_grad_norm is not None else None
             b.step += 1
