@@ -219,7 +219,8 @@ int imx_root_frame(int64_t num_envs, const float* quat_wxyz_d, const float* lin_
 int imx_mesh_create(const float* vertices_h, int64_t num_vertices, const uint32_t* triangles_h, int64_t num_triangles,
                     float cell_size, imx_mesh_t** out);
 void imx_mesh_destroy(imx_mesh_t* mesh);
-/* info[0..7] = nx, ny, num_triangles, num_cell_refs, max refs per cell, x0, y0, cell (floats bit-cast for 5..7) */
+/* info[0..7] = nx, ny, num_triangles, general triangle records, max refs per cell, lattice cells, general cells,
+ * cell size (float bits) */
 int imx_mesh_info(const imx_mesh_t* mesh, int64_t* info8);
 
 /* raycast_mesh (utils/warp/ops.py:24-127): closest hit per ray, misses = +inf / face -1. */

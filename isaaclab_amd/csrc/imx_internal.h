@@ -60,14 +60,25 @@ struct PlanView {
 PlanView imx_plan_view(const imx_plan* p);
 
 // ---- mesh ---------------------------------------------------------------------------------------------------------
+// Cells of the xy grid are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height scanner maps
+// to a handful of contiguous runs.  One int32 descriptor per cell:
+//   kind = desc & 3:  0 empty
+//                     1 LATTICE  the cell holds exactly the two triangles (a,b,c),(a,d,b) of one height-field quad
+//                                (convert_height_field_to_mesh topology); face ids = desc>>2 and +1; its corners sit in
+//                                the tile's 9x9 vertex pool: slot (py*9+px) = a, +1 = d, +9 = c, +10 = b.  A vertex is
+//                                stored once per tile and shared by the up to four cells around it (16 B / vertex).
+//                     2 GENERAL  count = (desc>>2)&63 triangle references starting at record desc>>8; one 48-byte record
+//                                per reference: ax ay az bx | by bz cx cy | cz face(int) 0 0
+//                     3 GENERAL_IND  the same through gtab[desc>>2] = {first record, count} (first >= 2^24 or count > 63)
+#define IMX_CELL_EMPTY 0
+#define IMX_CELL_LATTICE 1
+#define IMX_CELL_GENERAL 2
+#define IMX_CELL_GENERAL_IND 3
 struct MeshView {
-    // (num refs, 12) per-cell triangle records, grouped per cell: ax ay az bx | by bz cx cy | cz face(int) 0 0.
-    // 48 B = three 16-byte loads, no triangle-id indirection; a height-field mesh aligned with the grid has one
-    // reference per triangle, so nothing is duplicated in the common case.
-    const float4* tri_rec;
-    // (ntx*nty*64 + 1): cells are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height
-    // scanner maps to a handful of 6 KB runs instead of 17 row segments 190 KB apart
-    const int32_t* cell_start;
+    const int32_t* cell_desc;  // (ntx*nty*64)
+    const float4* tile_pool;   // (ntx*nty*81) xyz0
+    const int2* gtab;          // (general cells)
+    const float4* tri_rec;     // (general references, 3 x float4)
     int ntx, nty;
     int nx, ny;
     float x0, y0, cell, inv_cell;
@@ -75,10 +86,13 @@ struct MeshView {
 };
 struct imx_mesh {
     MeshView v{};
-    float4* d_tri_rec = nullptr;
-    int32_t* d_cell_start = nullptr;
-    int64_t num_refs = 0;
+    int32_t* d_cell_desc = nullptr;
+    float* d_tile_pool = nullptr;
+    int32_t* d_gtab = nullptr;
+    float* d_tri_rec = nullptr;
+    int64_t num_refs = 0;  // general triangle records
     int32_t max_refs = 0;
+    int64_t n_lattice = 0, n_general = 0;
 };
 // linear index of cell (ix, iy) in the 8x8-tiled layout
 static __host__ __device__ __forceinline__ int imx_cell_index(int ix, int iy, int ntx) {
@@ -145,12 +159,14 @@ IMX_DEV float wrap_to_pi(float a) {
 
 IMX_DEV float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
 
-// counter-based uniform [0,1): splitmix64 finaliser over (seed, step, element index); 24-bit mantissa like torch.rand
+// counter-based uniform [0,1): two rounds of a 32-bit multiply-xorshift hash (Wellons' "lowbias32") over
+// (seed, step, element index); 24-bit mantissa like torch.rand.  ~12 VALU ops (a 64-bit splitmix cost ~40).
 IMX_DEV float uniform01(uint64_t seed, uint32_t step, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(step + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+    uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    x += step * 0x9E3779B9u + 0x7F4A7C15u;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    x += step; x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-

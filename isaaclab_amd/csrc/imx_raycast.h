@@ -87,20 +87,34 @@ IMX_DEV void test_record(const WoopRay& r, const float4 q0, const float4 q1, con
     }
 }
 
+IMX_DEV void test_tri(const WoopRay& r, float4 a, float4 b, float4 c, int32_t f, float& best, int32_t& face) {
+    float t;
+    if (woop_hit(r, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, t)) {
+        if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+            best = t;
+            face = f;
+        }
+    }
+}
+
 IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int s = m.cell_start[c], e = m.cell_start[c + 1];
-    // two records per trip: their six 16-byte loads are independent and issue back to back (the usual cell of a
-    // height-field mesh holds exactly two triangles)
-    for (int k = s; k < e; k += 2) {
-        const int k1 = min(k + 1, e - 1);  // duplicate of k when the count is odd: closest-hit is idempotent
-        const float4* p0 = m.tri_rec + (size_t)k * 3;
-        const float4* p1 = m.tri_rec + (size_t)k1 * 3;
-        const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2];
-        const float4 b0 = p1[0], b1 = p1[1], b2 = p1[2];
-        test_record(r, a0, a1, a2, best, face);
-        test_record(r, b0, b1, b2, best, face);
+    const int32_t d = m.cell_desc[c];
+    const int kind = d & 3;
+    if (kind == IMX_CELL_LATTICE) {
+        const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
+        const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
+        const int32_t f0 = (int32_t)((uint32_t)d >> 2);
+        test_tri(r, va, vb, vc, f0, best, face);      // (a, b, c)
+        test_tri(r, va, vd, vb, f0 + 1, best, face);  // (a, d, b)
+    } else if (kind != IMX_CELL_EMPTY) {
+        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
+        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
+        for (int k = g.x; k < g.x + g.y; ++k) {
+            const float4* q = m.tri_rec + (size_t)k * 3;
+            test_record(r, q[0], q[1], q[2], best, face);
+        }
     }
 }
 
@@ -114,37 +128,63 @@ IMX_DEV int cell_of(float g, int& nb) {
 
 // Register-lean closest hit for a VERTICAL ray (dx = dy = 0): the Woop shear terms vanish (Sx = Sy = -+0, so
 // A[kx] - Sx*A[kz] == A[kx] bit for bit) and one 48-byte record is live at a time.  Same results as cast_ray().
+// one triangle, vertical ray: kx, ky = (y, x) when dz < 0 (flip), (x, y) otherwise
+IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_, float bz_, float cx_, float cy_, float cz_,
+                          int32_t f, float ox, float oy, float oz, bool flip, float Sz, float& best, int32_t& face) {
+    const float ax = ax_ - ox, ay = ay_ - oy, bx = bx_ - ox, by = by_ - oy, cx = cx_ - ox, cy = cy_ - oy;
+    const float Ax = flip ? ay : ax, Ay = flip ? ax : ay;
+    const float Bx = flip ? by : bx, By = flip ? bx : by;
+    const float Cx = flip ? cy : cx, Cy = flip ? cx : cy;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+    const float det = U + V + W;
+    if (det == 0.0f) return;
+    const float Az = Sz * (az_ - oz), Bz = Sz * (bz_ - oz), Cz = Sz * (cz_ - oz);
+    const float T = U * Az + V * Bz + W * Cz;
+    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return;
+    const float t = T * (1.0f / det);
+    if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+        best = t;
+        face = f;
+    }
+}
+
 IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz,
                            float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int s = m.cell_start[c], e = m.cell_start[c + 1];
-    for (int k = s; k < e; ++k) {
-        const float4* p = m.tri_rec + (size_t)k * 3;
-        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-        // kx, ky = (y, x) when dz < 0 (flip), (x, y) otherwise
-        const float ax = q0.x - ox, ay = q0.y - oy, bx = q0.w - ox, by = q1.x - oy, cx = q1.z - ox, cy = q1.w - oy;
-        const float Ax = flip ? ay : ax, Ay = flip ? ax : ay;
-        const float Bx = flip ? by : bx, By = flip ? bx : by;
-        const float Cx = flip ? cy : cx, Cy = flip ? cx : cy;
-        float U = Cx * By - Cy * Bx;
-        float V = Ax * Cy - Ay * Cx;
-        float W = Bx * Ay - By * Ax;
-        if (U == 0.0f || V == 0.0f || W == 0.0f) {
-            U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-            V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-            W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
-        }
-        if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
-        const float det = U + V + W;
-        if (det == 0.0f) continue;
-        const float Az = Sz * (q0.z - oz), Bz = Sz * (q1.y - oz), Cz = Sz * (q2.x - oz);
-        const float T = U * Az + V * Bz + W * Cz;
-        if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) continue;
-        const float t = T * (1.0f / det);
-        if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
-            best = t;
-            face = __float_as_int(q2.y);
+    // The pool address does not depend on the descriptor: issue all five loads together (one memory round trip for
+    // the common LATTICE case; the pool exists for every tile, so the speculative corner loads are always in bounds)
+    const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
+    const int32_t d = m.cell_desc[c];
+    const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
+    const int kind = d & 3;
+    if (kind == IMX_CELL_LATTICE) {  // the common case on a height-field terrain: descriptor + 4 shared corners
+        const int32_t f0 = (int32_t)((uint32_t)d >> 2);
+        vertical_tri(va.x, va.y, va.z, vb.x, vb.y, vb.z, vc.x, vc.y, vc.z, f0, ox, oy, oz, flip, Sz, best, face);
+        vertical_tri(va.x, va.y, va.z, vd.x, vd.y, vd.z, vb.x, vb.y, vb.z, f0 + 1, ox, oy, oz, flip, Sz, best, face);
+    } else if (kind != IMX_CELL_EMPTY) {
+        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
+        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
+        // two records per trip: their six 16-byte loads are independent and issue back to back; an odd tail repeats the
+        // last record (closest-hit is idempotent)
+        const int end = g.x + g.y;
+        for (int k = g.x; k < end; k += 2) {
+            const float4* p = m.tri_rec + (size_t)k * 3;
+            const float4* p2 = m.tri_rec + (size_t)min(k + 1, end - 1) * 3;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
+            vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
+                         best, face);
+            vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
+                         best, face);
         }
     }
 }

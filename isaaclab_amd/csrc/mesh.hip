@@ -1,6 +1,6 @@
 // Terrain mesh upload + 2-D uniform-grid build (host side, counting sort).  Replaces convert_to_warp_mesh /
 // wp.Mesh's BVH build (reference isaaclab/utils/warp/ops.py:130-145, called once at RayCaster init,
-// sensors/ray_caster/ray_caster.py:182-189).  Membership rule: see imx_raycast.h.
+// sensors/ray_caster/ray_caster.py:182-189).  Membership rule and cell encodings: see imx_raycast.h.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -25,7 +25,7 @@ static inline void cell_range(float lo, float hi, float origin, float inv_cell, 
 extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tris, int64_t F, float cell_size,
                                imx_mesh_t** out) {
     IMX_REQUIRE(verts && tris && out, "imx_mesh_create: null argument");
-    IMX_REQUIRE(V > 0 && F > 0 && F < (1ll << 31), "imx_mesh_create: empty or oversized mesh (V=%lld F=%lld)",
+    IMX_REQUIRE(V > 0 && F > 0 && F < (1ll << 29), "imx_mesh_create: empty or oversized mesh (V=%lld F=%lld)",
                 (long long)V, (long long)F);
     float xmin = INFINITY, ymin = INFINITY, xmax = -INFINITY, ymax = -INFINITY;
     for (int64_t i = 0; i < V; ++i) {
@@ -51,16 +51,16 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     }
     const float inv_cell = 1.0f / cell_size;
     const int ntx = (int)((nx + 7) / 8), nty = (int)((ny + 7) / 8);
-    const int64_t ncell = (int64_t)ntx * nty * 64;  // 8x8-tiled layout (imx_cell_index)
+    const int64_t ntile = (int64_t)ntx * nty;
+    const int64_t ncell = ntile * 64;  // 8x8-tiled layout (imx_cell_index)
 
+    // ---- pass 1: per-triangle cell ranges, per-cell reference counts (CSR), ascending triangle ids per cell
     std::vector<int32_t> start((size_t)ncell + 1, 0);
-    std::vector<float> tv((size_t)F * 9);  // host copy of the corners, packed per reference below
-    std::vector<int32_t> ra((size_t)F * 4);  // per-triangle cell ranges
+    std::vector<int32_t> ra((size_t)F * 4);
     for (int64_t f = 0; f < F; ++f) {
         float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
         for (int c = 0; c < 3; ++c) {
             const float* p = verts + 3 * (size_t)tris[3 * f + c];
-            tv[f * 9 + c * 3 + 0] = p[0]; tv[f * 9 + c * 3 + 1] = p[1]; tv[f * 9 + c * 3 + 2] = p[2];
             lox = std::min(lox, p[0]); hix = std::max(hix, p[0]);
             loy = std::min(loy, p[1]); hiy = std::max(hiy, p[1]);
         }
@@ -78,31 +78,126 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         start[c + 1] += start[c];
     }
     const int64_t nrefs = start[ncell];
-    // per-reference 48-byte records (see MeshView): ascending triangle id inside every cell -> deterministic tie-break
-    std::vector<float> recs((size_t)std::max<int64_t>(nrefs, 1) * 12, 0.0f);
-    std::vector<int32_t> cursor(start.begin(), start.end() - 1);
-    for (int64_t f = 0; f < F; ++f)
-        for (int iy = ra[f * 4 + 2]; iy <= ra[f * 4 + 3]; ++iy)
-            for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix) {
-                float* r = &recs[(size_t)(cursor[(size_t)imx_cell_index(ix, iy, ntx)]++) * 12];
-                memcpy(r, &tv[(size_t)f * 9], 9 * sizeof(float));
-                const int32_t fid = (int32_t)f;
-                memcpy(r + 9, &fid, 4);
+    std::vector<int32_t> refs((size_t)std::max<int64_t>(nrefs, 1));
+    {
+        std::vector<int32_t> cursor(start.begin(), start.end() - 1);
+        for (int64_t f = 0; f < F; ++f)
+            for (int iy = ra[f * 4 + 2]; iy <= ra[f * 4 + 3]; ++iy)
+                for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix) refs[cursor[(size_t)imx_cell_index(ix, iy, ntx)]++] = (int32_t)f;
+    }
+
+    // ---- pass 2: encode every cell.  LATTICE cells (the two triangles of one height-field quad,
+    // (a,b,c) + (a,d,b) with consecutive ids, each referenced by this cell only) keep just a descriptor: their four
+    // corners live once in the tile's 9x9 vertex pool, shared with the neighbouring cells.  Everything else becomes a
+    // GENERAL cell: gtab entry {first record, count} + one 48-byte record per reference.
+    std::vector<int32_t> desc((size_t)ncell, 0);
+    std::vector<float> pool((size_t)ntile * 81 * 4, 0.0f);
+    std::vector<uint8_t> pool_set((size_t)ntile * 81, 0);
+    std::vector<int32_t> gtab;
+    std::vector<float> recs;
+    int64_t n_lattice = 0, n_general = 0;
+    auto single_cell = [&](int32_t f) {
+        return ra[(size_t)f * 4] == ra[(size_t)f * 4 + 1] && ra[(size_t)f * 4 + 2] == ra[(size_t)f * 4 + 3];
+    };
+    for (int iy = 0; iy < (int)ny; ++iy)
+        for (int ix = 0; ix < (int)nx; ++ix) {
+            const int c = imx_cell_index(ix, iy, ntx);
+            const int n = start[c + 1] - start[c];
+            if (n == 0) continue;
+            const int32_t* r = &refs[start[c]];
+            bool lattice = false;
+            if (n == 2 && r[1] == r[0] + 1 && single_cell(r[0]) && single_cell(r[1])) {
+                const uint32_t* t0 = tris + 3 * (size_t)r[0];
+                const uint32_t* t1 = tris + 3 * (size_t)r[1];
+                if (t0[0] == t1[0] && t0[1] == t1[2]) {  // (a,b,c), (a,d,b)
+                    const int64_t tile = c >> 6;
+                    const int px = ix & 7, py = iy & 7;
+                    const uint32_t corner_v[4] = {t0[0], t1[1], t0[2], t0[1]};  // a->(0,0) d->(1,0) c->(0,1) b->(1,1)
+                    const int slot[4] = {py * 9 + px, py * 9 + px + 1, (py + 1) * 9 + px, (py + 1) * 9 + px + 1};
+                    bool ok = true;
+                    for (int k = 0; k < 4 && ok; ++k) {
+                        const size_t s = (size_t)tile * 81 + slot[k];
+                        if (pool_set[s]) ok = memcmp(&pool[s * 4], verts + 3 * (size_t)corner_v[k], 12) == 0;
+                    }
+                    if (ok) {
+                        for (int k = 0; k < 4; ++k) {
+                            const size_t s = (size_t)tile * 81 + slot[k];
+                            memcpy(&pool[s * 4], verts + 3 * (size_t)corner_v[k], 12);
+                            pool_set[s] = 1;
+                        }
+                        desc[c] = (int32_t)(((uint32_t)r[0] << 2) | IMX_CELL_LATTICE);
+                        lattice = true;
+                        ++n_lattice;
+                    }
+                }
             }
+            if (!lattice) {
+                const uint64_t first = recs.size() / 12;
+                if (first < (1u << 24) && n < 64) {  // first record and count inline: no second table look-up
+                    desc[c] = (int32_t)(((uint32_t)first << 8) | ((uint32_t)n << 2) | IMX_CELL_GENERAL);
+                } else {
+                    IMX_REQUIRE(gtab.size() / 2 < (1u << 29), "imx_mesh_create: too many general cells");
+                    desc[c] = (int32_t)(((uint32_t)(gtab.size() / 2) << 2) | IMX_CELL_GENERAL_IND);
+                    gtab.push_back((int32_t)first);
+                    gtab.push_back(n);
+                }
+                for (int k = 0; k < n; ++k) {
+                    const int32_t f = r[k];
+                    float rec[12] = {0};
+                    for (int cc = 0; cc < 3; ++cc) memcpy(&rec[cc * 3], verts + 3 * (size_t)tris[3 * (size_t)f + cc], 12);
+                    memcpy(&rec[9], &f, 4);
+                    recs.insert(recs.end(), rec, rec + 12);
+                }
+                ++n_general;
+            }
+        }
+    if (getenv("IMX_MESH_STATS")) {  // debugging aid: histogram of references per general cell
+        std::vector<int64_t> hist(16, 0), histv(16, 0);
+        int64_t degenerate = 0, total = 0;
+        for (int64_t c = 0; c < ncell; ++c) {
+            const int n = start[c + 1] - start[c];
+            if (n == 0 || (desc[c] & 3) == IMX_CELL_LATTICE) continue;
+            int nv = 0;
+            for (int k = 0; k < n; ++k) {
+                const uint32_t* t = tris + 3 * (size_t)refs[start[c] + k];
+                const float* a = verts + 3 * (size_t)t[0]; const float* b = verts + 3 * (size_t)t[1]; const float* cc = verts + 3 * (size_t)t[2];
+                const double area = (double)(b[0] - a[0]) * (cc[1] - a[1]) - (double)(b[1] - a[1]) * (cc[0] - a[0]);
+                if (area != 0.0) ++nv; else ++degenerate;
+                ++total;
+            }
+            hist[std::min(n, 15)]++; histv[std::min(nv, 15)]++;
+        }
+        fprintf(stderr, "[imx mesh] general cells by #refs:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)hist[i]);
+        fprintf(stderr, "\n[imx mesh] general cells by #non-degenerate refs:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)histv[i]);
+        fprintf(stderr, "\n[imx mesh] degenerate (zero xy-area) refs %lld of %lld\n", (long long)degenerate, (long long)total);
+    }
+    IMX_REQUIRE(recs.size() / 12 < (1ull << 31), "imx_mesh_create: too many general triangle records");
+    if (gtab.empty()) gtab.assign(2, 0);
+    if (recs.empty()) recs.assign(12, 0.0f);
 
     IMX_REQUIRE(imx_device_count() > 0, "imx_mesh_create: no GPU visible");
     auto m = std::make_unique<imx_mesh>();
-    IMX_HIP(hipMalloc((void**)&m->d_tri_rec, recs.size() * sizeof(float)));
-    IMX_HIP(hipMalloc((void**)&m->d_cell_start, start.size() * sizeof(int32_t)));
-    IMX_HIP(hipMemcpy(m->d_tri_rec, recs.data(), recs.size() * sizeof(float), hipMemcpyHostToDevice));
-    IMX_HIP(hipMemcpy(m->d_cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    m->v.tri_rec = m->d_tri_rec;
-    m->v.cell_start = m->d_cell_start;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        IMX_HIP(hipMalloc(dst, bytes));
+        IMX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up((void**)&m->d_cell_desc, desc.data(), desc.size() * 4) || up((void**)&m->d_tile_pool, pool.data(), pool.size() * 4) ||
+        up((void**)&m->d_gtab, gtab.data(), gtab.size() * 4) || up((void**)&m->d_tri_rec, recs.data(), recs.size() * 4))
+        return 1;
+    m->v.cell_desc = m->d_cell_desc;
+    m->v.tile_pool = reinterpret_cast<const float4*>(m->d_tile_pool);
+    m->v.gtab = reinterpret_cast<const int2*>(m->d_gtab);
+    m->v.tri_rec = reinterpret_cast<const float4*>(m->d_tri_rec);
     m->v.nx = (int)nx; m->v.ny = (int)ny; m->v.ntx = ntx; m->v.nty = nty;
     m->v.x0 = xmin; m->v.y0 = ymin; m->v.cell = cell_size; m->v.inv_cell = inv_cell;
     m->v.F = F;
-    m->num_refs = nrefs;
+    m->num_refs = (int64_t)(recs.size() / 12);
     m->max_refs = max_refs;
+    m->n_lattice = n_lattice;
+    m->n_general = n_general;
     *out = m.release();
     return 0;
 }
@@ -110,16 +205,17 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
 extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
     if (!m) return;
     if (m->d_tri_rec) (void)hipFree(m->d_tri_rec);
-    if (m->d_cell_start) (void)hipFree(m->d_cell_start);
+    if (m->d_cell_desc) (void)hipFree(m->d_cell_desc);
+    if (m->d_tile_pool) (void)hipFree(m->d_tile_pool);
+    if (m->d_gtab) (void)hipFree(m->d_gtab);
     delete m;
 }
 
 extern "C" int imx_mesh_info(const imx_mesh_t* m, int64_t* info8) {
     IMX_REQUIRE(m && info8, "imx_mesh_info: null argument");
     info8[0] = m->v.nx; info8[1] = m->v.ny; info8[2] = m->v.F; info8[3] = m->num_refs; info8[4] = m->max_refs;
+    info8[5] = m->n_lattice; info8[6] = m->n_general;
     int32_t b;
-    memcpy(&b, &m->v.x0, 4); info8[5] = b;
-    memcpy(&b, &m->v.y0, 4); info8[6] = b;
     memcpy(&b, &m->v.cell, 4); info8[7] = b;
     return 0;
 }

@@ -103,9 +103,16 @@ static inline StepScratch carve(void* base, int64_t N, int KA, int NT) {
     return s;
 }
 
+// per-env frame table written by k_frame, read by k_obs: IMX_ES_WORDS floats per env, behind the step scratch
+#define IMX_ES_WORDS 20
+static inline size_t frame_offset_bytes(const imx_plan_t* plan, int64_t N) {
+    const size_t b = 4 * step_scratch_words(N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
+    return (b + 255) & ~(size_t)255;
+}
+
 extern "C" size_t imx_plan_scratch_bytes(const imx_plan_t* plan, int64_t num_envs) {
     if (!plan || num_envs <= 0) return 0;
-    return 4 * step_scratch_words(num_envs, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1) + 256;
+    return frame_offset_bytes(plan, num_envs) + (size_t)num_envs * IMX_ES_WORDS * sizeof(float) + 256;
 }
 
 // ------------------------------------------------------------------------------------------------- action affine
@@ -489,49 +496,46 @@ IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restr
     return v;
 }
 
-// One single-wave BLOCK = 64 output columns of one environment (ray columns first in xcol).  The wave derives the
-// env's root-frame vectors and the scanner yaw (uniform loads, ~300 VALU ops), parks them in LDS (a register
-// spill area: no barrier, the block is one wave), and every lane then is an independent, register-light stream: xcol (four 16-byte loads) -> value -> noise/clip/scale -> obs[e*D + c].
-// Occupancy, not instruction-level parallelism, hides the ray-cast's dependent loads (cell table -> triangle
-// records): ~50 VGPRs, 16 K waves for 4096 envs.  Consecutive lanes write consecutive floats of one obs row.
-#define IMX_ES_WORDS 20
-template <bool GENERAL_RAYS>
+// k_frame: one lane per env -- root-frame vectors (ArticulationData.root_lin_vel_b / root_ang_vel_b /
+// projected_gravity_b), sensor position and the yaw-only sensor quaternion (yaw_quat, utils/math.py:521-542), once per
+// env per step instead of once per wave of k_obs (PMC: the transcendental prologue was ~40 % of k_obs's VALU work).
 __global__ void __launch_bounds__(64)
-k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ noise_u,
-      uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
-    __shared__ float es[IMX_ES_WORDS];
-    const int nchunk = (P.D + 63) >> 6;  // 64-lane blocks per env
-    const int64_t e = blockIdx.x / nchunk;
-    const int chunk = (int)(blockIdx.x - e * nchunk);
+k_frame(PlanView P, int64_t N, imx_state_t S, float* __restrict__ frame) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[e];
+    float4 o[5];
+    quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_lin_vel_w[e * 3], S.root_lin_vel_w[e * 3 + 1],
+                        S.root_lin_vel_w[e * 3 + 2], o[0].x, o[0].y, o[0].z);
+    quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_ang_vel_w[e * 3], S.root_ang_vel_w[e * 3 + 1],
+                        S.root_ang_vel_w[e * 3 + 2], o[0].w, o[1].x, o[1].y);
+    quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, P.gx, P.gy, P.gz, o[1].z, o[1].w, o[2].x);
+    o[2].y = S.root_pos_w[e * 3]; o[2].z = S.root_pos_w[e * 3 + 1]; o[2].w = S.root_pos_w[e * 3 + 2];
+    o[3] = q4;
+    o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(q4.x, q4.y, q4.z, q4.w, o[4].x, o[4].y);
+    float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dst[k] = o[k];
+}
+
+// k_obs: one BLOCK = one environment, one lane = one output column (ray columns first in xcol).  No prologue, no
+// barrier: the env's 20-float frame is read with wave-uniform loads (scalar cache), then every lane is an independent,
+// register-light stream: xcol (four 16-byte loads) -> value -> noise/clip/scale -> obs[e*D + c]; consecutive lanes
+// write consecutive floats of one obs row.  The ray path is cast_ray_vertical (imx_raycast.h): cell descriptor and
+// the four shared lattice corners are loaded together -- one dependent memory level per ray on height-field terrain.
+template <bool GENERAL_RAYS>
+__global__ void __launch_bounds__(256)
+k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
+      const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
+    const int64_t e = blockIdx.x;
     const int32_t* __restrict__ W = P.w;
     const int D = P.D, J = P.J;
-    {  // all lanes redundantly (uniform addresses: one transaction each); the block is ONE wave, so the LDS hand-off
-       // below needs no barrier
-        const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[e];
-        float v[IMX_ES_WORDS];
-        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_lin_vel_w[e * 3], S.root_lin_vel_w[e * 3 + 1],
-                            S.root_lin_vel_w[e * 3 + 2], v[0], v[1], v[2]);
-        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, S.root_ang_vel_w[e * 3], S.root_ang_vel_w[e * 3 + 1],
-                            S.root_ang_vel_w[e * 3 + 2], v[3], v[4], v[5]);
-        quat_rotate_inverse(q4.x, q4.y, q4.z, q4.w, P.gx, P.gy, P.gz, v[6], v[7], v[8]);
-        v[9] = S.root_pos_w[e * 3]; v[10] = S.root_pos_w[e * 3 + 1]; v[11] = S.root_pos_w[e * 3 + 2];
-        v[12] = q4.x; v[13] = q4.y; v[14] = q4.z; v[15] = q4.w;
-        v[16] = 1.0f; v[17] = 0.0f;
-        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(q4.x, q4.y, q4.z, q4.w, v[16], v[17]);
-        if (threadIdx.x < 18) {
-            float x = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) x = (threadIdx.x == k) ? v[k] : x;
-            es[threadIdx.x] = x;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
     const uint32_t step = (uint32_t)Bf.counters[2];
     const float pz = es[11];
-    const int i = chunk * 64 + (int)threadIdx.x;
-    if (i < D) {
+    const float yw = es[16], yz = es[17], px = es[9], py = es[10];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
         const XCol x = load_xcol(W, P.xcol_off, i);
         const int c = x.a.x, op = x.a.y, j = x.a.z, flags = x.a.w, aux = x.c.z;
         float v = 0.0f;
@@ -561,12 +565,12 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
                 const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
                 float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
                 if (P.ray_yaw_only) {
-                    quat_apply_yaw_only(es[16], es[17], lx, ly, lz, sx, sy, sz);
+                    quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
                 } else {  // ray_caster.py:249-252: full orientation for starts and directions
                     quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
                     quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
                 }
-                sx += es[9]; sy += es[10]; sz += pz;
+                sx += px; sy += py; sz += pz;
                 float t;
                 int32_t face;
                 float hx, hy, hz;
@@ -734,16 +738,19 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     MeshView mv{};
     if (mesh) mv = mesh->v;
-    const unsigned nchunk = (unsigned)((plan->D + 63) / 64);  // one-wave blocks: (env, 64 columns)
+    const int bs = plan->D <= 64 ? 64 : (plan->D <= 128 ? 128 : (plan->D <= 192 ? 192 : 256));  // one block per env
     const PlanView pv = imx_plan_view(plan);
+    IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
+    float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
+    hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, frame);
     // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
     const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
     if (vertical)
-        hipLaunchKernelGGL(k_obs<false>, dim3((unsigned)N * nchunk), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, noise_u_d,
-                           seed, enable_corruption, ray_hits_out_d);
+        hipLaunchKernelGGL(k_obs<false>, dim3((unsigned)N), dim3(bs), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame,
+                           noise_u_d, seed, enable_corruption, ray_hits_out_d);
     else
-        hipLaunchKernelGGL(k_obs<true>, dim3((unsigned)N * nchunk), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, noise_u_d,
-                           seed, enable_corruption, ray_hits_out_d);
+        hipLaunchKernelGGL(k_obs<true>, dim3((unsigned)N), dim3(bs), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame,
+                           noise_u_d, seed, enable_corruption, ray_hits_out_d);
     IMX_HIP(hipGetLastError());
     return 0;
 }

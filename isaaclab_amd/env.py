@@ -67,6 +67,7 @@ class TerrainMesh:
         info = (ctypes.c_int64 * 8)()
         check(lib().imx_mesh_info(self._h, info))
         self.nx, self.ny, self.num_triangles, self.num_refs, self.max_refs = (int(info[i]) for i in range(5))
+        self.num_lattice_cells, self.num_general_cells = int(info[5]), int(info[6])
         self.num_vertices = v.shape[0]
 
     @property

@@ -16,7 +16,7 @@ def timeit(fn, n=200):
 dev = torch.device("cuda:0")
 fx, env, ntri = build_env("Isaac-Velocity-Rough-Anymal-C-v0", 4096, dev, 42, 4, (10, 20))
 env.reset()
-print("mesh", env.terrain.nx, env.terrain.ny, env.terrain.num_refs, env.terrain.max_refs)
+print("mesh", env.terrain.nx, env.terrain.ny, "general refs", env.terrain.num_refs, "max", env.terrain.max_refs, "lattice cells", env.terrain.num_lattice_cells, "general cells", env.terrain.num_general_cells)
 print("k_obs normal            %.1f us" % timeit(env._compute_observations))
 env.plan.enable_corruption = False
 print("k_obs no noise          %.1f us" % timeit(env._compute_observations))
