@@ -236,20 +236,22 @@ int imx_gae(int64_t T, int64_t N, const float* rewards_d, const float* values_d,
             float* advantages_d, void* scratch_d, imx_stream_t stream);
 
 /* rsl_rl PPO.update elementwise part: surrogate / clipped value / entropy losses and the KL estimate for a
- * minibatch of M samples with A action dims.  fwd writes out4 = {surrogate_loss, value_loss, entropy_mean, kl_mean};
- * bwd writes d(loss)/d(mu), d(loss)/d(sigma), d(loss)/d(value) for
- * loss = surrogate + value_loss_coef*value_loss - entropy_coef*entropy.  PARITY UNPINNED (rsl_rl absent). */
+ * minibatch of M samples with A action dims.  sigma_stride = A for a per-sample (M,A) std, 0 for the shared (A) std
+ * parameter.  fwd writes out8 = {surrogate_loss, value_loss, entropy_mean, kl_mean, loss, -, -, -} with
+ * loss = surrogate + value_loss_coef*value_loss - entropy_coef*entropy, and (optional) accum5 += {value_loss,
+ * surrogate, entropy, kl, 1}; bwd writes grad_scale * d(loss)/d(mu), /d(sigma) (per sample, (M,A)), /d(value).
+ * PARITY UNPINNED (rsl_rl absent). */
 size_t imx_ppo_scratch_bytes(int64_t M);
-int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, const float* actions_d,
-                     const float* old_logp_d, const float* old_mu_d, const float* old_sigma_d,
-                     const float* advantages_d, const float* returns_d, const float* values_d,
-                     const float* old_values_d, float clip_param, int use_clipped_value_loss, float* out4_d,
-                     void* scratch_d, imx_stream_t stream);
-int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, const float* actions_d,
-                     const float* old_logp_d, const float* advantages_d, const float* returns_d,
-                     const float* values_d, const float* old_values_d, float clip_param,
-                     int use_clipped_value_loss, float value_loss_coef, float entropy_coef, float grad_scale,
-                     float* dmu_d, float* dsigma_d, float* dvalue_d, imx_stream_t stream);
+int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, int64_t sigma_stride,
+                     const float* actions_d, const float* old_logp_d, const float* old_mu_d, const float* old_sigma_d,
+                     const float* advantages_d, const float* returns_d, const float* values_d, const float* old_values_d,
+                     float clip_param, int use_clipped_value_loss, float value_loss_coef, float entropy_coef,
+                     float* out8_d, float* accum5_d, void* scratch_d, imx_stream_t stream);
+int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, int64_t sigma_stride,
+                     const float* actions_d, const float* old_logp_d, const float* advantages_d, const float* returns_d,
+                     const float* values_d, const float* old_values_d, float clip_param, int use_clipped_value_loss,
+                     float value_loss_coef, float entropy_coef, float grad_scale, float* dmu_d, float* dsigma_d,
+                     float* dvalue_d, imx_stream_t stream);
 
 /* torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (as used by rsl_rl PPO.update) on one flat fp32 bucket.
  * lr_d / grad_norm_d are DEVICE scalars (adaptive-KL learning rate, ||g||_2); grad_norm_d NULL = no clipping.
@@ -257,6 +259,19 @@ int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma
 int imx_adam_step(int64_t n, float* param_d, const float* grad_d, float* exp_avg_d, float* exp_avg_sq_d,
                   const float* lr_d, const float* grad_norm_d, float max_norm, float beta1, float beta2, float eps,
                   int64_t step, imx_stream_t stream);
+
+/* The same with the whole schedule on the device (capturable in a hipGraph): state8_d = {lr, step, beta1^t, beta2^t,
+ * clip coef, lr/bias1, sqrt(bias2), -}.  A one-thread kernel applies rsl_rl's adaptive-KL rule to lr when kl_d != NULL
+ * (lr /= 1.5 if kl > 2*desired_kl; lr *= 1.5 if 0 < kl < desired_kl/2; bounds [1e-5, 1e-2]), advances the Adam step
+ * and derives the clip coefficient from grad_norm_d; a second kernel applies Adam to the bucket. */
+int imx_adam_update(int64_t n, float* param_d, const float* grad_d, float* exp_avg_d, float* exp_avg_sq_d, float* state8_d,
+                    const float* kl_d, float desired_kl, const float* grad_norm_d, float max_norm, float beta1,
+                    float beta2, float eps, imx_stream_t stream);
+
+/* rsl_rl RolloutStorage.mini_batch_generator: dst[k][r, :] = src[k][idx[r], :] for n <= 12 fp32 arrays of
+ * width_floats[k] columns, one launch.  src_d / dst_d / width_floats are HOST arrays of device pointers / widths. */
+int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
+                    const int32_t* width_floats, imx_stream_t stream);
 
 #ifdef __cplusplus
 }

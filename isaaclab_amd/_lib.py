@@ -59,11 +59,15 @@ _SIGNATURES = {
     "imx_gae": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
                         c_void_p, c_void_p, c_void_p]),
     "imx_ppo_scratch_bytes": (c_size_t, [c_int64]),
-    "imx_ppo_loss_fwd": (c_int, [c_int64, c_int64] + [c_void_p] * 10 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
-    "imx_ppo_loss_bwd": (c_int, [c_int64, c_int64] + [c_void_p] * 8 + [c_float, c_int, c_float, c_float, c_float, c_void_p,
-                                                                      c_void_p, c_void_p, c_void_p]),
+    "imx_ppo_loss_fwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 8 + [c_float, c_int, c_float, c_float,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imx_ppo_loss_bwd": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 6 + [c_float, c_int, c_float, c_float,
+                                c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                               c_float, c_int64, c_void_p]),
+    "imx_adam_update": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float,
+                                c_float, c_float, c_float, c_void_p]),
+    "imx_gather_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

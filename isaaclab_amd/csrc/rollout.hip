@@ -183,12 +183,25 @@ k_ppo_fwd(int64_t M, int A, const float* __restrict__ mu, const float* __restric
     if (threadIdx.x < 4) part[4 * blockIdx.x + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-__global__ void k_ppo_finish(int nblk, float inv_m, const float* __restrict__ part, float* __restrict__ out4) {
+// out8 = {surrogate, value_loss, entropy_mean, kl_mean, loss, 0, 0, 0}; accum (optional, 5 floats) += {value_loss,
+// surrogate, entropy, kl, 1} (the running means rsl_rl logs per update)
+__global__ void k_ppo_finish(int nblk, float inv_m, float vcoef, float ecoef, const float* __restrict__ part,
+                             float* __restrict__ out8, float* __restrict__ accum) {
+    __shared__ float r[4];
     const int q = threadIdx.x;
-    if (q >= 4) return;
-    float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += part[4 * b + q];
-    out4[q] = s * inv_m;
+    if (q < 4) {
+        float s = 0.0f;
+        for (int b = 0; b < nblk; ++b) s += part[4 * b + q];
+        r[q] = s * inv_m;
+        out8[q] = r[q];
+    }
+    __syncthreads();
+    if (q == 0) {
+        out8[4] = r[0] + vcoef * r[1] - ecoef * r[2];
+        if (accum) {
+            accum[0] += r[1]; accum[1] += r[0]; accum[2] += r[2]; accum[3] += r[3]; accum[4] += 1.0f;
+        }
+    }
 }
 
 // d/d(mu, sigma, value) of  mean(sur) + vcoef*mean(vl) - ecoef*mean(ent), times grad_scale (the upstream grad)
@@ -238,33 +251,36 @@ k_ppo_bwd(int64_t M, int A, const float* __restrict__ mu, const float* __restric
     dval[i] = vcoef * dv * inv_m;
 }
 
-extern "C" int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu, const float* sigma, const float* act,
-                                const float* old_logp, const float* old_mu, const float* old_sigma, const float* adv,
-                                const float* ret, const float* val, const float* old_val, float clip, int clipped_value,
-                                float* out4, void* scratch, imx_stream_t stream) {
+extern "C" int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu, const float* sigma, int64_t sigma_stride,
+                                const float* act, const float* old_logp, const float* old_mu, const float* old_sigma,
+                                const float* adv, const float* ret, const float* val, const float* old_val, float clip,
+                                int clipped_value, float vcoef, float ecoef, float* out8, float* accum, void* scratch,
+                                imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && A > 0 && A <= 4096, "imx_ppo_loss_fwd: bad sizes M=%lld A=%lld", (long long)M, (long long)A);
-    IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && out4 && scratch, "imx_ppo_loss_fwd: null argument");
+    IMX_REQUIRE(sigma_stride == 0 || sigma_stride == A, "imx_ppo_loss_fwd: sigma_stride must be 0 (shared std) or A");
+    IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && out8 && scratch, "imx_ppo_loss_fwd: null argument");
     IMX_REQUIRE(!clipped_value || old_val, "imx_ppo_loss_fwd: clipped value loss needs old values");
     IMX_REQUIRE((old_mu == nullptr) == (old_sigma == nullptr), "imx_ppo_loss_fwd: old_mu/old_sigma must come together");
     const unsigned nblk = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(k_ppo_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma, (int)A, act, old_logp,
-                       old_mu, old_sigma, adv, ret, val, old_val, clip, clipped_value, (float*)scratch);
-    hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)nblk, 1.0f / (float)M,
-                       (const float*)scratch, out4);
+    hipLaunchKernelGGL(k_ppo_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma, (int)sigma_stride, act,
+                       old_logp, old_mu, old_sigma, adv, ret, val, old_val, clip, clipped_value, (float*)scratch);
+    hipLaunchKernelGGL(k_ppo_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)nblk, 1.0f / (float)M, vcoef, ecoef,
+                       (const float*)scratch, out8, accum);
     IMX_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu, const float* sigma, const float* act,
-                                const float* old_logp, const float* adv, const float* ret, const float* val,
-                                const float* old_val, float clip, int clipped_value, float vcoef, float ecoef,
-                                float gscale, float* dmu, float* dsigma, float* dval, imx_stream_t stream) {
+extern "C" int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu, const float* sigma, int64_t sigma_stride,
+                                const float* act, const float* old_logp, const float* adv, const float* ret, const float* val,
+                                const float* old_val, float clip, int clipped_value, float vcoef, float ecoef, float gscale,
+                                float* dmu, float* dsigma, float* dval, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && A > 0, "imx_ppo_loss_bwd: bad sizes");
+    IMX_REQUIRE(sigma_stride == 0 || sigma_stride == A, "imx_ppo_loss_bwd: sigma_stride must be 0 (shared std) or A");
     IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && dmu && dsigma && dval, "imx_ppo_loss_bwd: null argument");
     IMX_REQUIRE(!clipped_value || old_val, "imx_ppo_loss_bwd: clipped value loss needs old values");
     hipLaunchKernelGGL(k_ppo_bwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma,
-                       (int)A, act, old_logp, adv, ret, val, old_val, clip, clipped_value, vcoef, ecoef, gscale, dmu, dsigma,
-                       dval);
+                       (int)sigma_stride, act, old_logp, adv, ret, val, old_val, clip, clipped_value, vcoef, ecoef, gscale, dmu,
+                       dsigma, dval);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -301,6 +317,101 @@ extern "C" int imx_adam_step(int64_t n, float* p, const float* g, float* m, floa
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, lr_d, grad_norm_d, max_norm,
                        beta1, beta2, eps, bias1, sb2);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- Adam, device-side schedule
+// state (8 floats, device): [0] lr  [1] step count  [2] beta1^t  [3] beta2^t  [4] clip coef  [5] lr/bias1  [6] sqrt(bias2)
+// k_adam_prepare (one thread) = rsl_rl's adaptive-KL learning-rate rule + Adam step bookkeeping + clip_grad_norm_'s
+// coefficient, all from device scalars: nothing of the schedule lives on the host, so the whole update is capturable.
+__global__ void k_adam_prepare(float* __restrict__ st, const float* __restrict__ kl_d, float desired_kl,
+                               const float* __restrict__ norm_d, float max_norm, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lr = st[0];
+    if (kl_d) {  // PPO.update 'adaptive': lr /= 1.5 if kl > 2*desired; lr *= 1.5 if 0 < kl < desired/2
+        const float kl = kl_d[0];
+        if (kl > desired_kl * 2.0f) lr = fmaxf(1.0e-5f, lr / 1.5f);
+        else if (kl < desired_kl / 2.0f && kl > 0.0f) lr = fminf(1.0e-2f, lr * 1.5f);
+    }
+    const float p1 = st[2] * b1, p2 = st[3] * b2;
+    st[0] = lr;
+    st[1] += 1.0f;
+    st[2] = p1;
+    st[3] = p2;
+    st[4] = norm_d ? fminf(max_norm / (norm_d[0] + 1.0e-6f), 1.0f) : 1.0f;
+    st[5] = lr / (1.0f - p1);
+    st[6] = sqrtf(1.0f - p2);
+}
+
+__global__ void __launch_bounds__(256)
+k_adam_apply(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+             const float* __restrict__ st, float b1, float b2, float eps) {
+    const float coef = st[4], step_size = st[5], sqrt_bias2 = st[6];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / sqrt_bias2 + eps));
+    }
+}
+
+extern "C" int imx_adam_update(int64_t n, float* p, const float* g, float* m, float* v, float* state8, const float* kl_d,
+                               float desired_kl, const float* grad_norm_d, float max_norm, float beta1, float beta2,
+                               float eps, imx_stream_t stream) {
+    IMX_REQUIRE(n > 0 && p && g && m && v && state8, "imx_adam_update: bad arguments");
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, state8, kl_d, desired_kl, grad_norm_d,
+                       max_norm, beta1, beta2);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_adam_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (const float*)state8, beta1,
+                       beta2, eps);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- minibatch gather
+// RolloutStorage.mini_batch_generator: obs[idx], actions[idx], values[idx], ... -- one launch for all (<= 12) arrays.
+// The arrays are treated as one virtual row of sum(width) floats per sample; lane = (sample, column) so the stores
+// are contiguous per array and the loads are contiguous inside a gathered row.
+struct GatherArgs {
+    const float* src[12];
+    float* dst[12];
+    int width[12];
+    int offset[13];  // prefix sums of width
+    int n;
+};
+__global__ void __launch_bounds__(256) k_gather_rows(int64_t M, const int64_t* __restrict__ idx, GatherArgs a) {
+    const int total = a.offset[a.n];
+    const int64_t nel = M * total;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / total;
+        const int c = (int)(i - r * total);
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 12; ++q) k += (q < a.n && c >= a.offset[q]) ? 1 : 0;
+        const int cc = c - a.offset[k];
+        a.dst[k][r * a.width[k] + cc] = a.src[k][idx[r] * a.width[k] + cc];
+    }
+}
+
+extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
+                               const int32_t* width_floats, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && idx_d && n > 0 && n <= 12 && src_d && dst_d && width_floats, "imx_gather_rows: bad arguments");
+    GatherArgs a;
+    a.n = n;
+    a.offset[0] = 0;
+    for (int k = 0; k < 12; ++k) {
+        a.src[k] = k < n ? (const float*)src_d[k] : nullptr;
+        a.dst[k] = k < n ? (float*)dst_d[k] : nullptr;
+        a.width[k] = k < n ? width_floats[k] : 0;
+        IMX_REQUIRE(k >= n || (a.src[k] && a.dst[k] && a.width[k] > 0), "imx_gather_rows: array %d is null or empty", k);
+        a.offset[k + 1] = a.offset[k] + a.width[k];
+    }
+    const int64_t nel = M * a.offset[n];
+    const unsigned grid = (unsigned)std::min<int64_t>((nel + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, idx_d, a);
     IMX_HIP(hipGetLastError());
     return 0;
 }

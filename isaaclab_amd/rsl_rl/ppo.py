@@ -1,14 +1,18 @@
 """PPO (upstream ``rsl_rl/algorithms/ppo.py`` @ v2.3.1 -- third-party, absent from the reference tree; PARITY UNPINNED,
 restated in oracle/rsl_rl_oracle.py; cfg: reference isaaclab_rl/rsl_rl/rl_cfg.py:107-163).
 
-MI355X-first changes (results unchanged):
-  * the elementwise loss (log-prob, entropy, KL, clipped surrogate, clipped value loss) is one HIP forward and one
-    HIP backward kernel (``imx_ppo_loss_fwd/bwd``) behind a ``torch.autograd.Function``;
-  * all parameters are views of ONE flat fp32 bucket, all gradients views of one flat gradient bucket: the
-    data-parallel all-reduce is a single RCCL call on that bucket (+1 slot carrying the KL estimate), no
+MI355X-first structure of ``update()`` (same arithmetic as upstream):
+  * all parameters are views of ONE flat fp32 bucket, all gradients views of one flat gradient bucket (+1 slot that
+    carries the KL estimate): the data-parallel exchange is a single RCCL ``all_reduce`` on that bucket, no
     ``torch.cat`` / scatter per minibatch;
-  * grad-norm clipping + Adam are one kernel (``imx_adam_step``) reading the learning rate and the gradient norm
-    from device memory, so the adaptive-KL schedule never synchronises with the host.
+  * the backward pass is written out (no autograd graph): per MLP layer one GEMM writes ``dW`` *directly into the flat
+    gradient bucket* (no ``zero_grad``, no ``AccumulateGrad`` adds), one reduction ``db``, one GEMM ``dX`` and one
+    ``elu_backward``; the GEMMs stay in torch (hipBLASLt / rocBLAS, recorded TunableOp selections);
+  * the elementwise loss (log-prob, entropy, KL, clipped surrogate, clipped value loss) is one HIP forward + one HIP
+    backward kernel (``imx_ppo_loss_fwd/bwd``) reading the shared ``std`` vector with stride 0;
+  * the adaptive-KL learning-rate rule, Adam step bookkeeping, ``clip_grad_norm_`` and ``Adam.step`` are two kernels
+    (``imx_adam_update``) working from device scalars: ``update()`` never synchronises with the host.
+``fused_ppo_loss`` (autograd form) is kept for users who build their own update on torch autograd.
 """
 
 from __future__ import annotations
@@ -16,12 +20,14 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import _lib
 from .._lib import check, lib
 from .storage import RolloutStorage
 
 
+# ---------------------------------------------------------------------------------------------------- fused loss (autograd form)
 class _FusedPPOLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, sigma, value, actions, old_logp, old_mu, old_sigma, adv, ret, old_value, clip, clipped, vcoef, ecoef):
@@ -30,17 +36,17 @@ class _FusedPPOLoss(torch.autograd.Function):
         mu_c, sg_c, v_c = mu.contiguous(), sigma.contiguous(), value.contiguous()
         args = [t.contiguous() for t in (actions, old_logp, old_mu, old_sigma, adv, ret, old_value)]
         actions, old_logp, old_mu, old_sigma, adv, ret, old_value = args
-        out4 = torch.empty(4, device=mu.device)
+        out8 = torch.empty(8, device=mu.device)
         scratch = torch.empty(int(L.imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device=mu.device)
-        stream = _lib.current_stream(mu.device)
-        check(L.imx_ppo_loss_fwd(M, A, mu_c.data_ptr(), sg_c.data_ptr(), actions.data_ptr(), old_logp.data_ptr(),
+        check(L.imx_ppo_loss_fwd(M, A, mu_c.data_ptr(), sg_c.data_ptr(), A, actions.data_ptr(), old_logp.data_ptr(),
                                  old_mu.data_ptr(), old_sigma.data_ptr(), adv.data_ptr(), ret.data_ptr(), v_c.data_ptr(),
-                                 old_value.data_ptr(), float(clip), int(clipped), out4.data_ptr(), scratch.data_ptr(), stream))
+                                 old_value.data_ptr(), float(clip), int(clipped), float(vcoef), float(ecoef),
+                                 out8.data_ptr(), None, scratch.data_ptr(), _lib.current_stream(mu.device)))
         ctx.save_for_backward(mu_c, sg_c, v_c, actions, old_logp, adv, ret, old_value)
         ctx.cfg = (float(clip), int(clipped), float(vcoef), float(ecoef))
-        loss = out4[0] + vcoef * out4[1] - ecoef * out4[2]
-        ctx.mark_non_differentiable(out4)
-        return loss, out4
+        stats = out8[:4]
+        ctx.mark_non_differentiable(stats)
+        return out8[4], stats
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
@@ -48,15 +54,11 @@ class _FusedPPOLoss(torch.autograd.Function):
         clip, clipped, vcoef, ecoef = ctx.cfg
         M, A = mu.shape
         dmu, dsigma, dvalue = torch.empty_like(mu), torch.empty_like(sigma), torch.empty_like(value)
-        check(lib().imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), actions.data_ptr(), old_logp.data_ptr(),
+        check(lib().imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), A, actions.data_ptr(), old_logp.data_ptr(),
                                      adv.data_ptr(), ret.data_ptr(), value.data_ptr(), old_value.data_ptr(), clip, clipped,
                                      vcoef, ecoef, 1.0, dmu.data_ptr(), dsigma.data_ptr(), dvalue.data_ptr(),
                                      _lib.current_stream(mu.device)))
-        if not _FusedPPOLoss.assume_unit_grad:
-            dmu, dsigma, dvalue = dmu * g_loss, dsigma * g_loss, dvalue * g_loss
-        return (dmu, dsigma, dvalue) + (None,) * 11
-
-    assume_unit_grad = False
+        return (dmu * g_loss, dsigma * g_loss, dvalue * g_loss) + (None,) * 11
 
 
 def fused_ppo_loss(mu, sigma, actions, old_logp, old_mu, old_sigma, adv, ret, value, old_value, clip_param,
@@ -66,6 +68,7 @@ def fused_ppo_loss(mu, sigma, actions, old_logp, old_mu, old_sigma, adv, ret, va
                                use_clipped_value_loss, value_loss_coef, entropy_coef)
 
 
+# ---------------------------------------------------------------------------------------------------- flat buckets
 class FlatParams:
     """Re-homes every parameter (and gradient) of ``module`` into one contiguous fp32 bucket."""
 
@@ -84,7 +87,6 @@ class FlatParams:
             off += n
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.step = 0
 
     def zero_grad(self):
         self.grad.zero_()
@@ -97,11 +99,60 @@ def allreduce_mean_(bucket_grad: torch.Tensor, world_size: int) -> None:
 
 
 def adaptive_lr_(lr: torch.Tensor, kl: torch.Tensor, desired_kl: float) -> None:
-    """rsl_rl PPO.update 'adaptive' schedule, evaluated on the device (no host sync, identical on every rank
-    because ``kl`` is the all-reduced value): lr /= 1.5 if kl > 2*desired; lr *= 1.5 if 0 < kl < desired/2."""
+    """rsl_rl PPO.update 'adaptive' schedule as tensor ops (reference semantics of ``k_adam_prepare``; identical on
+    every rank because ``kl`` is the all-reduced value): lr /= 1.5 if kl > 2*desired; lr *= 1.5 if 0 < kl < desired/2."""
     up = torch.clamp(lr * 1.5, max=1e-2)
     down = torch.clamp(lr / 1.5, min=1e-5)
     lr.copy_(torch.where(kl > desired_kl * 2.0, down, torch.where((kl < desired_kl / 2.0) & (kl > 0.0), up, lr)))
+
+
+# ---------------------------------------------------------------------------------------------------- explicit MLP fwd/bwd
+def _mlp_layers(seq: nn.Sequential):
+    """[(Linear, activation module or None)] of an actor/critic ``nn.Sequential`` built by ``ActorCritic``."""
+    mods = list(seq)
+    out = []
+    for i, m in enumerate(mods):
+        if isinstance(m, nn.Linear):
+            act = mods[i + 1] if i + 1 < len(mods) and not isinstance(mods[i + 1], nn.Linear) else None
+            out.append((m, act))
+    return out
+
+
+def mlp_forward(layers, x):
+    """Returns (output, saved layer inputs).  ELU layers run in place on the GEMM output."""
+    saved = [x]
+    h = x
+    for lin, act in layers:
+        z = torch.addmm(lin.bias, h, lin.weight.t())  # GEMM + bias epilogue (hipBLASLt)
+        if act is None:
+            h = z
+        elif isinstance(act, nn.ELU):
+            h = F.elu(z, alpha=act.alpha, inplace=True)
+            saved.append(h)
+        else:
+            h = act(z)
+            saved.append((z, h))
+    return h, saved
+
+
+def mlp_backward(layers, saved, dout):
+    """Writes dW/db of every layer straight into ``param.grad`` (views of the flat bucket)."""
+    d = dout
+    for i in range(len(layers) - 1, -1, -1):
+        lin, _ = layers[i]
+        x = saved[i] if not isinstance(saved[i], tuple) else saved[i][1]
+        torch.mm(d.t(), x, out=lin.weight.grad)
+        torch.sum(d, dim=0, out=lin.bias.grad)
+        if i > 0:
+            dx = torch.mm(d, lin.weight)
+            prev_act = layers[i - 1][1]
+            if isinstance(prev_act, nn.ELU):  # ELU'(z) from the saved output: y > 0 ? 1 : y + alpha
+                d = torch.ops.aten.elu_backward(dx, prev_act.alpha, 1.0, 1.0, True, saved[i])
+            else:
+                z, _h = saved[i]
+                with torch.enable_grad():
+                    zz = z.detach().requires_grad_(True)
+                    (d,) = torch.autograd.grad(prev_act(zz), zz, dx)
 
 
 class PPO:
@@ -127,13 +178,18 @@ class PPO:
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self.desired_kl, self.schedule = desired_kl, schedule
         self.normalize_advantage_per_mini_batch = normalize_advantage_per_mini_batch
-        self._lr = torch.full((1,), float(learning_rate), device=self.device)  # device-side: adaptive schedule w/o sync
         self.betas, self.eps = (0.9, 0.999), 1e-8
+        # device-side optimiser state: [lr, step, beta1^t, beta2^t, clip coef, lr/bias1, sqrt(bias2), -]
+        self._adam = torch.tensor([float(learning_rate), 0.0, 1.0, 1.0, 1.0, 0.0, 1.0, 0.0], device=self.device)
         self._stats = torch.zeros(5, device=self.device)  # running sums: value, surrogate, entropy, kl, count
+        self._out8 = torch.zeros(8, device=self.device)
+        self._actor_layers = _mlp_layers(self.policy.actor)
+        self._critic_layers = _mlp_layers(self.policy.critic)
+        self._ws: dict = {}
 
     @property
     def learning_rate(self) -> float:
-        return float(self._lr.item())
+        return float(self._adam[0].item())
 
     # ---- storage / rollout -----------------------------------------------------------------------------------
     def init_storage(self, training_type, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, actions_shape):
@@ -175,39 +231,69 @@ class PPO:
         allreduce_mean_(self.bucket.grad, self.gpu_world_size)
 
     # ---- update ----------------------------------------------------------------------------------------------------
+    def _workspace(self, M: int, A: int):
+        ws = self._ws.get((M, A))
+        if ws is None:
+            dev = self.device
+            ws = dict(dmu=torch.empty(M, A, device=dev), dsigma=torch.empty(M, A, device=dev), dvalue=torch.empty(M, 1, device=dev),
+                      scratch=torch.empty(int(lib().imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device=dev))
+            self._ws[(M, A)] = ws
+        return ws
+
+    def minibatch_step(self, obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
+        """Forward, loss, explicit backward into the flat gradient bucket (no optimiser step)."""
+        L = lib()
+        pol = self.policy
+        stream = _lib.current_stream(self.device)
+        M, A = actions.shape
+        ws = self._workspace(M, A)
+        mu, saved_a = mlp_forward(self._actor_layers, obs)
+        value, saved_c = mlp_forward(self._critic_layers, critic_obs)
+        if pol.noise_std_type == "scalar":
+            sigma, sstride = pol.std, 0
+        else:
+            sigma, sstride = torch.exp(pol.log_std).expand_as(mu).contiguous(), A
+        check(L.imx_ppo_loss_fwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
+                                 old_mu.data_ptr(), old_sigma.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
+                                 value.data_ptr(), target_values.data_ptr(), float(self.clip_param),
+                                 int(self.use_clipped_value_loss), float(self.value_loss_coef), float(self.entropy_coef),
+                                 self._out8.data_ptr(), self._stats.data_ptr(), ws["scratch"].data_ptr(), stream))
+        check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
+                                 advantages.data_ptr(), returns.data_ptr(), value.data_ptr(), target_values.data_ptr(),
+                                 float(self.clip_param), int(self.use_clipped_value_loss), float(self.value_loss_coef),
+                                 float(self.entropy_coef), 1.0, ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(),
+                                 ws["dvalue"].data_ptr(), stream))
+        if pol.noise_std_type == "scalar":
+            torch.sum(ws["dsigma"], dim=0, out=pol.std.grad)
+        else:
+            torch.sum(ws["dsigma"] * sigma, dim=0, out=pol.log_std.grad)
+        mlp_backward(self._actor_layers, saved_a, ws["dmu"])
+        mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
+        self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
+        return self._out8
+
+    @torch.no_grad()
     def update(self):
         b = self.bucket
         L = lib()
         stream = _lib.current_stream(self.device)
         self._stats.zero_()
-        _FusedPPOLoss.assume_unit_grad = True
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
-        for (obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma) in gen:
+        for batch in gen:
             if self.normalize_advantage_per_mini_batch:
-                with torch.no_grad():
-                    advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
-            mu = self.policy.actor(obs)
-            sigma = self.policy._std(mu)
-            value = self.policy.critic(critic_obs)
-            loss, stats = fused_ppo_loss(mu, sigma, actions, old_logp, old_mu, old_sigma, advantages, returns, value,
-                                         target_values, self.clip_param, self.use_clipped_value_loss,
-                                         self.value_loss_coef, self.entropy_coef)
-            b.zero_grad()
-            loss.backward()
-            b.grad[-1] = stats[3]  # KL estimate rides in the gradient bucket
+                batch = list(batch)
+                adv = batch[4]
+                batch[4] = (adv - adv.mean()) / (adv.std() + 1e-8)
+            self.minibatch_step(*batch)
             if self.is_multi_gpu:
                 self.reduce_parameters()
-            if self.desired_kl is not None and self.schedule == "adaptive":
-                adaptive_lr_(self._lr, b.grad[-1], self.desired_kl)
             g = b.grad[:b.numel]
             norm = torch.linalg.vector_norm(g).reshape(1) if self.max_grad_norm is not None else None
-            b.step += 1
-            check(L.imx_adam_step(b.numel, b.flat.data_ptr(), g.data_ptr(), b.exp_avg.data_ptr(), b.exp_avg_sq.data_ptr(),
-                                  self._lr.data_ptr(), _lib.ptr(norm), float(self.max_grad_norm or 0.0), self.betas[0],
-                                  self.betas[1], self.eps, b.step, stream))
-            self._stats[:4] += torch.stack([stats[1], stats[0], stats[2], stats[3]])
-            self._stats[4] += 1
-        _FusedPPOLoss.assume_unit_grad = False
+            check(L.imx_adam_update(b.numel, b.flat.data_ptr(), g.data_ptr(), b.exp_avg.data_ptr(), b.exp_avg_sq.data_ptr(),
+                                    self._adam.data_ptr(), b.grad[-1:].data_ptr() if adaptive else None,
+                                    float(self.desired_kl or 0.0), _lib.ptr(norm), float(self.max_grad_norm or 0.0),
+                                    self.betas[0], self.betas[1], self.eps, stream))
         self.storage.clear()
         return self._stats  # device tensor; .tolist() only when the caller wants to log
 

@@ -170,7 +170,7 @@ class OnPolicyRunner:
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         torch.save({"model_state_dict": self.alg.policy.state_dict(),
                     "optimizer_state_dict": {"exp_avg": self.alg.bucket.exp_avg, "exp_avg_sq": self.alg.bucket.exp_avg_sq,
-                                             "step": self.alg.bucket.step, "lr": self.alg._lr},
+                                             "adam_state": self.alg._adam},
                     "iter": self.current_learning_iteration, "infos": infos}, path)
 
     def load(self, path: str, load_optimizer: bool = True):
@@ -182,8 +182,7 @@ class OnPolicyRunner:
             o = d["optimizer_state_dict"]
             self.alg.bucket.exp_avg.copy_(o["exp_avg"])
             self.alg.bucket.exp_avg_sq.copy_(o["exp_avg_sq"])
-            self.alg.bucket.step = int(o["step"])
-            self.alg._lr.copy_(o["lr"])
+            self.alg._adam.copy_(o["adam_state"])
         self.current_learning_iteration = d.get("iter", 0)
         return d.get("infos")
 

@@ -96,20 +96,36 @@ class RolloutStorage:
                     self.returns, self.advantages, self._gae_scratch)
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        """Yields (obs, critic_obs, actions, values, advantages, returns, old_log_prob, old_mu, old_sigma) minibatches
+        of a random permutation of the T*N transitions; the nine gathers are ONE ``imx_gather_rows`` launch into
+        reusable buffers (valid until the next minibatch is requested)."""
+        import ctypes
+
         batch_size = self.num_envs * self.num_transitions_per_env
-        mini_batch_size = batch_size // num_mini_batches
-        indices = torch.randperm(num_mini_batches * mini_batch_size, requires_grad=False, device=self.device)
-        observations = self.observations.flatten(0, 1)
-        privileged = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else observations
-        actions = self.actions.flatten(0, 1)
-        values = self.values.flatten(0, 1)
-        returns = self.returns.flatten(0, 1)
-        old_logp = self.actions_log_prob.flatten(0, 1)
-        advantages = self.advantages.flatten(0, 1)
-        old_mu = self.mu.flatten(0, 1)
-        old_sigma = self.sigma.flatten(0, 1)
+        M = batch_size // num_mini_batches
+        indices = torch.randperm(num_mini_batches * M, requires_grad=False, device=self.device)
+        srcs = [self.observations.flatten(0, 1)]
+        if self.privileged_observations is not None:
+            srcs.append(self.privileged_observations.flatten(0, 1))
+        srcs += [self.actions.flatten(0, 1), self.values.flatten(0, 1), self.advantages.flatten(0, 1),
+                 self.returns.flatten(0, 1), self.actions_log_prob.flatten(0, 1), self.mu.flatten(0, 1),
+                 self.sigma.flatten(0, 1)]
+        key = (M, len(srcs))
+        if getattr(self, "_mb_key", None) != key:
+            self._mb_dst = [torch.empty(M, s.shape[1], device=self.device) for s in srcs]
+            self._mb_key = key
+        dst = self._mb_dst
+        n = len(srcs)
+        src_p = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        dst_p = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dst])
+        widths = (ctypes.c_int32 * n)(*[s.shape[1] for s in srcs])
+        L = lib()
+        stream = _lib.current_stream(torch.device(self.device))
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
-                idx = indices[i * mini_batch_size:(i + 1) * mini_batch_size]
-                yield (observations[idx], privileged[idx], actions[idx], values[idx], advantages[idx], returns[idx],
-                       old_logp[idx], old_mu[idx], old_sigma[idx])
+                idx = indices[i * M:(i + 1) * M]
+                check(L.imx_gather_rows(M, idx.data_ptr(), n, src_p, dst_p, widths, stream))
+                if self.privileged_observations is not None:
+                    yield tuple(dst)
+                else:
+                    yield (dst[0], dst[0]) + tuple(dst[1:])

@@ -119,3 +119,98 @@ def test_ppo_loss_matches_autograd(libimx, M, A):
         assert_close(mu_g.grad * M, mu_c.grad * M, 1e-4, "dmu")
         assert_close(sg_g.grad * M, sg_c.grad * M, 1e-4, "dsigma")
         assert_close(v_g.grad * M, v_c.grad * M, 1e-4, "dvalue")
+
+
+def _tiny_ppo(device="cuda:0", D=37, A=5, hidden=(64, 32)):
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    torch.manual_seed(3)
+    pol = ActorCritic(D, D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.7)
+    return PPO(pol, num_learning_epochs=1, num_mini_batches=1, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3,
+               entropy_coef=0.005, max_grad_norm=1.0, device=device)
+
+
+def test_explicit_backward_matches_autograd(libimx):
+    """PPO.minibatch_step (hand-written backward into the flat bucket) vs torch autograd through the same modules."""
+    from oracle.rsl_rl_oracle import ppo_losses
+
+    M, D, A = 1000, 37, 5
+    alg = _tiny_ppo()
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn(M, D, generator=g).cuda()
+    act = torch.randn(M, A, generator=g).cuda()
+    old_mu = (0.3 * torch.randn(M, A, generator=g)).cuda()
+    old_sigma = (torch.rand(M, A, generator=g) * 0.5 + 0.5).cuda()
+    old_logp = torch.distributions.Normal(old_mu, old_sigma).log_prob(act).sum(-1, keepdim=True)
+    adv, ret, old_val = (torch.randn(M, 1, generator=g).cuda() for _ in range(3))
+    with torch.no_grad():
+        out8 = alg.minibatch_step(obs, obs, act, old_val, adv, ret, old_logp, old_mu, old_sigma).clone()
+    got = alg.bucket.grad.clone()
+    # autograd reference on the same parameters
+    pol = alg.policy
+    alg.bucket.zero_grad()
+    mu = pol.actor(obs)
+    sigma = pol.std.expand_as(mu)
+    val = pol.critic(obs)
+    s, v, e, kl = ppo_losses(mu, sigma, act, old_logp, old_mu, old_sigma, adv, ret, val, old_val, 0.2, True)
+    loss = s + 1.0 * v - 0.005 * e
+    loss.backward()
+    n = alg.bucket.numel
+    assert_close(out8[:5], torch.stack([s, v, e, kl, loss]).detach(), 1e-5, "loss terms")
+    ref = alg.bucket.grad[:n]
+    err = (got[:n] - ref).abs().max() / ref.abs().max()
+    assert float(err) < 1e-5, f"flat gradient bucket: max err / max |g| = {float(err):.2e}"  # fp32 GEMM summation order
+    assert_close(got[:n], ref, 1e-5, "flat gradient bucket")
+    assert abs(float(got[n]) - float(kl)) < 1e-6  # KL rides in the trailing slot
+
+
+def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx):
+    from isaaclab_amd import _lib
+
+    n = 10_007
+    g0 = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g0).cuda()
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = torch.tensor([1e-3, 0, 1, 1, 1, 0, 1, 0], dtype=torch.float32, device="cuda")
+    lr_ref = 1e-3
+    for step, kl in enumerate([0.004, 0.03, 0.012, 0.0, 0.05, 0.001]):
+        grad = (torch.randn(n, generator=g0) * (3.0 if step % 2 else 0.01)).cuda()
+        ref_p.grad = grad.clone()
+        # upstream order: LR decision from KL, then clip, then step
+        if kl > 0.02: lr_ref = max(1e-5, lr_ref / 1.5)
+        elif 0.0 < kl < 0.005: lr_ref = min(1e-2, lr_ref * 1.5)
+        for gr in opt.param_groups: gr["lr"] = lr_ref
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        norm = torch.linalg.vector_norm(grad).reshape(1)
+        kl_t = torch.tensor([kl], device="cuda")
+        _lib.check(libimx.imx_adam_update(n, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(),
+                                          kl_t.data_ptr(), 0.01, norm.data_ptr(), 1.0, 0.9, 0.999, 1e-8,
+                                          torch.cuda.current_stream().cuda_stream))
+        assert abs(float(state[0]) - lr_ref) < 1e-9 and int(state[1]) == step + 1
+        assert_close(p, ref_p.detach(), 1e-5, f"adam step {step}")
+
+
+def test_minibatch_generator_is_a_permutation_gather(libimx):
+    from isaaclab_amd.rsl_rl.storage import RolloutStorage
+
+    T, N, D, A = 6, 50, 7, 3
+    st = RolloutStorage(N, T, [D], [0], [A], device="cuda:0")
+    g = torch.Generator().manual_seed(0)
+    for name in ("observations", "actions", "values", "advantages", "returns", "actions_log_prob", "mu", "sigma"):
+        getattr(st, name).copy_(torch.randn(getattr(st, name).shape, generator=g))
+    # tag every transition with its flat index so that the permutation can be read back
+    st.values.copy_(torch.arange(T * N, dtype=torch.float32).view(T, N, 1))
+    seen = []
+    for (obs, cobs, act, val, adv, ret, logp, mu, sg) in st.mini_batch_generator(4, 2):
+        assert obs.shape == (T * N // 4, D) and cobs is obs
+        idx = val[:, 0].long()
+        assert torch.equal(obs, st.observations.flatten(0, 1)[idx]) and torch.equal(act, st.actions.flatten(0, 1)[idx])
+        assert torch.equal(adv, st.advantages.flatten(0, 1)[idx]) and torch.equal(sg, st.sigma.flatten(0, 1)[idx])
+        assert torch.equal(logp, st.actions_log_prob.flatten(0, 1)[idx]) and torch.equal(mu, st.mu.flatten(0, 1)[idx])
+        seen.append(idx.clone())
+    first_epoch = torch.cat(seen[:4]).sort().values
+    assert torch.equal(first_epoch.cpu(), torch.arange(T * N))  # every transition exactly once per epoch
