@@ -273,6 +273,21 @@ int imx_adam_update(int64_t n, float* param_d, const float* grad_d, float* exp_a
 int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
                     const int32_t* width_floats, imx_stream_t stream);
 
+/* rsl_rl PPO.act after the actor / critic GEMMs: sample a = mu + std*N(0,1) (counter-based in-kernel generator keyed by
+ * seed and *step_counter_d), log-prob, and the transition written into slot t of the RolloutStorage (obs, actions,
+ * log-prob, mu, sigma, value); actions_env_d (optional) receives a second copy for env.step.  PARITY UNPINNED. */
+int imx_policy_act(int64_t N, int64_t A, int64_t D, const float* mu_d, const float* std_d, const float* value_d,
+                   const float* obs_d, uint64_t seed, const int32_t* step_counter_d, float* actions_out_d,
+                   float* logp_out_d, float* mu_out_d, float* sigma_out_d, float* values_out_d, float* obs_out_d,
+                   float* actions_env_d, imx_stream_t stream);
+
+/* RslRlVecEnvWrapper.step dones (isaaclab_rl/rsl_rl/vecenv_wrapper.py:178) + rsl_rl PPO.process_env_step time-out
+ * bootstrap (rewards += gamma * values * time_outs) + the runner's episode statistics, into slot t of the storage. */
+int imx_rollout_post(int64_t N, const float* reward_d, const uint8_t* terminated_d, const uint8_t* truncated_d,
+                     const float* value_t_d, float gamma, int bootstrap_time_outs, float* rewards_out_d,
+                     uint8_t* dones_out_d, int64_t* dones_long_d, float* cur_reward_sum_d, float* cur_ep_len_d,
+                     float* ep_stats3_d, imx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -415,3 +415,103 @@ extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const voi
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- rollout step fusions
+// imx_policy_act = PPO.act after the two MLPs (upstream ppo.py::act + actor_critic.py::act/get_actions_log_prob):
+//   a = mu + std * eps, eps ~ N(0,1)   (distribution.sample(); in-kernel counter-based Box-Muller)
+//   log_prob = sum_a( -(a-mu)^2/(2 std^2) - log std - 0.5 log 2pi )
+// and the write of the transition (obs, actions, log-prob, mu, sigma, value) straight into slot t of the storage.
+__global__ void __launch_bounds__(256)
+k_policy_act(int64_t N, int A, int D, const float* __restrict__ mu, const float* __restrict__ std_a,
+             const float* __restrict__ value, const float* __restrict__ obs, uint64_t seed,
+             const int32_t* __restrict__ step_d, float* __restrict__ act_out, float* __restrict__ logp_out,
+             float* __restrict__ mu_out, float* __restrict__ sigma_out, float* __restrict__ val_out,
+             float* __restrict__ obs_out, float* __restrict__ act_env) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t step = step_d ? (uint32_t)step_d[0] : 0u;
+    for (int64_t e = tid; e < N; e += nth) {
+        float logp = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            const float m = mu[e * A + a], s = std_a[a];
+            const float u1 = 1.0f - uniform01(seed, step, (uint64_t)(e * A + a) * 2);        // (0,1]
+            const float u2 = uniform01(seed ^ 0x5851F42D4C957F2Dull, step, (uint64_t)(e * A + a) * 2 + 1);
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+            const float x = m + s * z;
+            const float d = x - m;
+            logp += -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI;
+            act_out[e * A + a] = x;
+            if (act_env) act_env[e * A + a] = x;
+            mu_out[e * A + a] = m;
+            sigma_out[e * A + a] = s;
+        }
+        logp_out[e] = logp;
+        val_out[e] = value[e];
+    }
+    const int64_t nobs = N * D;
+    for (int64_t i = tid; i < nobs; i += nth) obs_out[i] = obs[i];
+}
+
+extern "C" int imx_policy_act(int64_t N, int64_t A, int64_t D, const float* mu_d, const float* std_d, const float* value_d,
+                              const float* obs_d, uint64_t seed, const int32_t* step_counter_d, float* actions_out_d,
+                              float* logp_out_d, float* mu_out_d, float* sigma_out_d, float* values_out_d,
+                              float* obs_out_d, float* actions_env_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && A > 0 && D > 0, "imx_policy_act: bad sizes");
+    IMX_REQUIRE(mu_d && std_d && value_d && obs_d && actions_out_d && logp_out_d && mu_out_d && sigma_out_d &&
+                    values_out_d && obs_out_d, "imx_policy_act: null argument");
+    const unsigned grid = (unsigned)std::min<int64_t>((N * D + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_policy_act, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, (int)A, (int)D, mu_d, std_d, value_d,
+                       obs_d, seed, step_counter_d, actions_out_d, logp_out_d, mu_out_d, sigma_out_d, values_out_d, obs_out_d,
+                       actions_env_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+// imx_rollout_post = RslRlVecEnvWrapper.step's dones + PPO.process_env_step's time-out bootstrap + the runner's
+// episode book-keeping, writing slot t of the storage:
+//   dones = terminated | truncated;  rewards_t = rew + gamma * value_t * time_out;  episode sums / lengths / counts.
+// ep_stats (3 floats) accumulates finished episodes' {sum reward, sum length, count} with float atomics (logging only).
+__global__ void __launch_bounds__(256)
+k_rollout_post(int64_t N, const float* __restrict__ rew, const uint8_t* __restrict__ terminated,
+               const uint8_t* __restrict__ truncated, const float* __restrict__ value_t, float gamma, int bootstrap,
+               float* __restrict__ rew_out, uint8_t* __restrict__ dones_out, int64_t* __restrict__ dones_long,
+               float* __restrict__ cur_rew, float* __restrict__ cur_len, float* __restrict__ ep_stats) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s_r = 0.0f, s_l = 0.0f, s_c = 0.0f;
+    if (e < N) {
+        const bool to = truncated[e] != 0, done = to || terminated[e] != 0;
+        const float r = rew[e];
+        rew_out[e] = bootstrap ? r + gamma * (value_t[e] * (to ? 1.0f : 0.0f)) : r;
+        dones_out[e] = done ? 1 : 0;
+        if (dones_long) dones_long[e] = done ? 1 : 0;
+        if (cur_rew) {
+            const float cr = cur_rew[e] + r, cl = cur_len[e] + 1.0f;
+            if (done) { s_r = cr; s_l = cl; s_c = 1.0f; }
+            cur_rew[e] = done ? 0.0f : cr;
+            cur_len[e] = done ? 0.0f : cl;
+        }
+    }
+    if (ep_stats) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s_r += __shfl_xor(s_r, o, 64); s_l += __shfl_xor(s_l, o, 64); s_c += __shfl_xor(s_c, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && s_c > 0.0f) {
+            atomicAdd(&ep_stats[0], s_r); atomicAdd(&ep_stats[1], s_l); atomicAdd(&ep_stats[2], s_c);
+        }
+    }
+}
+
+extern "C" int imx_rollout_post(int64_t N, const float* reward_d, const uint8_t* terminated_d, const uint8_t* truncated_d,
+                                const float* value_t_d, float gamma, int bootstrap_time_outs, float* rewards_out_d,
+                                uint8_t* dones_out_d, int64_t* dones_long_d, float* cur_reward_sum_d, float* cur_ep_len_d,
+                                float* ep_stats3_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && reward_d && terminated_d && truncated_d && value_t_d && rewards_out_d && dones_out_d,
+                "imx_rollout_post: bad arguments");
+    IMX_REQUIRE((cur_reward_sum_d == nullptr) == (cur_ep_len_d == nullptr), "imx_rollout_post: episode buffers come together");
+    hipLaunchKernelGGL(k_rollout_post, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, reward_d,
+                       terminated_d, truncated_d, value_t_d, gamma, bootstrap_time_outs, rewards_out_d, dones_out_d,
+                       dones_long_d, cur_reward_sum_d, cur_ep_len_d, ep_stats3_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

@@ -58,6 +58,7 @@ class OnPolicyRunner:
         self._cur_episode_length = torch.zeros(N, device=self.device)
         self._ep_stats = torch.zeros(3, device=self.device)  # finished episodes: sum reward, sum length, count
         self._obs = obs
+        self._act_seed = int(train_cfg.get("seed", 42)) * 1000003 + self.gpu_global_rank
         self.collection_time = self.learn_time = 0.0
 
     # ---- distributed ---------------------------------------------------------------------------------------------
@@ -81,7 +82,17 @@ class OnPolicyRunner:
             torch.cuda.set_device(self.gpu_local_rank)
 
     # ---- rollout ---------------------------------------------------------------------------------------------------
+    def _fusable(self) -> bool:
+        from ..env import ManagerBasedRLEnv
+        from .vecenv_wrapper import RslRlVecEnvWrapper
+
+        return (isinstance(self.env, RslRlVecEnvWrapper) and isinstance(self.env.unwrapped, ManagerBasedRLEnv)
+                and self.privileged_obs_type is None and self.alg.policy.noise_std_type == "scalar"
+                and self.device.type == "cuda")
+
     def _rollout(self):
+        if self._fusable():
+            return self._rollout_fused()
         obs = self._obs
         for _ in range(self.num_steps_per_env):
             actions = self.alg.act(obs, obs)
@@ -96,6 +107,39 @@ class OnPolicyRunner:
             self._ep_stats[2] += done_f.sum()
             self._cur_reward_sum *= 1.0 - done_f
             self._cur_episode_length *= 1.0 - done_f
+        if self._graph_capturing:
+            self._obs_out.copy_(obs)
+        return obs
+
+    def _rollout_fused(self):
+        """Per step: 2 MLP forwards (torch GEMMs) + imx_policy_act + the 4 env kernels + imx_rollout_post; every
+        transition is written straight into its storage slot (no Transition object, no per-field copies)."""
+        from .. import _lib
+        from .._lib import check, lib
+        from .ppo import mlp_forward
+
+        L = lib()
+        alg, env, st = self.alg, self.env.unwrapped, self.alg.storage
+        pol = alg.policy
+        N, A, D = env.num_envs, env.plan.action_dim, env.plan.obs_dim
+        stream = _lib.current_stream(self.device)
+        step_ptr = env._counters[2:3].data_ptr()
+        bootstrap = 0 if env.is_finite_horizon else 1
+        obs = self._obs
+        for t in range(self.num_steps_per_env):
+            mu, _ = mlp_forward(alg._actor_layers, obs)
+            value, _ = mlp_forward(alg._critic_layers, obs)
+            check(L.imx_policy_act(N, A, D, mu.data_ptr(), pol.std.data_ptr(), value.data_ptr(), obs.data_ptr(),
+                                   self._act_seed, step_ptr, st.actions[t].data_ptr(), st.actions_log_prob[t].data_ptr(),
+                                   st.mu[t].data_ptr(), st.sigma[t].data_ptr(), st.values[t].data_ptr(),
+                                   st.observations[t].data_ptr(), None, stream))
+            obs_dict, rew, terminated, truncated, _ = env.step(st.actions[t])
+            check(L.imx_rollout_post(N, rew.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), st.values[t].data_ptr(),
+                                     float(alg.gamma), bootstrap, st.rewards[t].data_ptr(), st.dones[t].data_ptr(), None,
+                                     self._cur_reward_sum.data_ptr(), self._cur_episode_length.data_ptr(),
+                                     self._ep_stats.data_ptr(), stream))
+            obs = obs_dict["policy"]
+        st.step = self.num_steps_per_env
         if self._graph_capturing:
             self._obs_out.copy_(obs)
         return obs

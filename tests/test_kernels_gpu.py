@@ -214,3 +214,63 @@ def test_minibatch_generator_is_a_permutation_gather(libimx):
         seen.append(idx.clone())
     first_epoch = torch.cat(seen[:4]).sort().values
     assert torch.equal(first_epoch.cpu(), torch.arange(T * N))  # every transition exactly once per epoch
+
+
+def test_policy_act_samples_and_logprob(libimx):
+    from isaaclab_amd import _lib
+
+    N, A, D = 4096, 12, 20
+    g = torch.Generator().manual_seed(2)
+    mu = torch.randn(N, A, generator=g).cuda()
+    std = (torch.rand(A, generator=g) * 0.8 + 0.2).cuda()
+    value = torch.randn(N, 1, generator=g).cuda()
+    obs = torch.randn(N, D, generator=g).cuda()
+    step = torch.tensor([7], dtype=torch.int32, device="cuda")
+    out = {k: torch.empty(N, w, device="cuda") for k, w in dict(act=A, logp=1, mu=A, sigma=A, val=1, obs=D, env=A).items()}
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(seed):
+        _lib.check(libimx.imx_policy_act(N, A, D, mu.data_ptr(), std.data_ptr(), value.data_ptr(), obs.data_ptr(), seed,
+                                         step.data_ptr(), out["act"].data_ptr(), out["logp"].data_ptr(), out["mu"].data_ptr(),
+                                         out["sigma"].data_ptr(), out["val"].data_ptr(), out["obs"].data_ptr(),
+                                         out["env"].data_ptr(), s))
+
+    run(123)
+    a1 = out["act"].clone()
+    z = (a1 - mu) / std
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02 and float(z.abs().max()) < 6.5
+    assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.05  # neighbouring draws uncorrelated
+    ref_logp = torch.distributions.Normal(mu, std.expand_as(mu)).log_prob(a1).sum(-1, keepdim=True)
+    assert_close(out["logp"], ref_logp, 1e-5, "log_prob")
+    assert torch.equal(out["mu"], mu) and torch.equal(out["sigma"], std.expand_as(mu)) and torch.equal(out["val"], value)
+    assert torch.equal(out["obs"], obs) and torch.equal(out["env"], a1)
+    run(123)
+    assert torch.equal(out["act"], a1)  # counter-based: same (seed, step) -> same draws
+    step += 1
+    run(123)
+    assert not torch.equal(out["act"], a1)
+
+
+def test_rollout_post_bootstrap_and_episode_stats(libimx):
+    from isaaclab_amd import _lib
+    from oracle.rsl_rl_oracle import bootstrap_time_outs
+
+    N = 1000
+    g = torch.Generator().manual_seed(4)
+    rew = torch.randn(N, generator=g).cuda()
+    val = torch.randn(N, 1, generator=g).cuda()
+    term = (torch.rand(N, generator=g) < 0.1).cuda()
+    trunc = (torch.rand(N, generator=g) < 0.1).cuda()
+    rew_out = torch.empty(N, 1, device="cuda"); dones = torch.empty(N, 1, dtype=torch.uint8, device="cuda")
+    dl = torch.empty(N, dtype=torch.long, device="cuda")
+    cur_r, cur_l = torch.rand(N, generator=g).cuda(), torch.randint(0, 50, (N,), generator=g).float().cuda()
+    cr0, cl0 = cur_r.clone(), cur_l.clone()
+    stats = torch.zeros(3, device="cuda")
+    _lib.check(libimx.imx_rollout_post(N, rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), val.data_ptr(), 0.99, 1,
+                                       rew_out.data_ptr(), dones.data_ptr(), dl.data_ptr(), cur_r.data_ptr(), cur_l.data_ptr(),
+                                       stats.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert_close(rew_out[:, 0], bootstrap_time_outs(rew, val, trunc, 0.99), 1e-6, "time-out bootstrap")
+    d = term | trunc
+    assert torch.equal(dones[:, 0].bool(), d) and torch.equal(dl, d.long())
+    assert_close(stats, torch.stack([((cr0 + rew) * d).sum(), ((cl0 + 1) * d).sum(), d.sum().float()]), 1e-5, "episode stats")
+    assert_close(cur_r, (cr0 + rew) * (~d), 1e-6, "running reward") and assert_close(cur_l, (cl0 + 1) * (~d), 0, "running length") is None
