@@ -150,13 +150,13 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
 }
 
 // ------------------------------------------------------------------------------------------------- terminations + rewards
-// Block = 64 consecutive envs x 4 waves.  Lane l of every wave owns env 64*blockIdx + l.  Every wave evaluates the
+// Block = 64 consecutive envs x IMX_TR_WAVES waves.  Lane l of every wave owns env 64*blockIdx + l.  Every wave evaluates the
 // (cheap) termination terms, so each knows its envs' reset flags; the reward terms are dealt round-robin to the four
 // waves (4x the loads in flight per env), each wave finishing its own terms completely (value, episodic sum,
 // step_reward, reset-log partial).  The per-term values meet in LDS and wave 0 adds them IN TERM ORDER, so the
 // reward is bit-identical to a single-wave sequential evaluation.
-#define IMX_TR_WAVES 4
-__global__ void __launch_bounds__(256)
+#define IMX_TR_WAVES 8
+__global__ void __launch_bounds__(64 * IMX_TR_WAVES)
 k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc) {
     extern __shared__ float s_val[];  // [nrew][64]
     const int lane = threadIdx.x & 63;
@@ -394,16 +394,22 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     // -- last block finishes: ordered concatenation of the per-group id lists + log reductions (deterministic order)
     __shared__ int s_last;
     __shared__ int s_scan[IMX_TR_WAVES];
-    __threadfence();  // release this block's partials (agent scope)
+    // producer side (cdna_hip_programming.md G16, R1): every storing wave drains its stores, the block meets at the
+    // barrier, ONE lane releases at agent scope and takes the ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int ticket = atomicAdd(&Bf.counters[1], 1);
         s_last = (ticket == (int)gridDim.x - 1);
+        if (s_last) {  // consumer side: one agent-scope acquire, completed before the barrier releases the readers
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();  // acquire the other blocks' partials
     const int nw = (int)((N + 63) / 64);
     const int T = blockDim.x;
     const int t = threadIdx.x;

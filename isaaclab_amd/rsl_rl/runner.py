@@ -64,7 +64,7 @@ class OnPolicyRunner:
     # ---- distributed ---------------------------------------------------------------------------------------------
     def _configure_multi_gpu(self):
         self.gpu_world_size = int(os.getenv("WORLD_SIZE", "1"))
-        self.is_distributed = self.gpu_world_size > 1
+        self.is_distributed = self.gpu_world_size > 1 or os.getenv("IMX_FORCE_DIST") == "1"
         if not self.is_distributed:
             self.gpu_local_rank = self.gpu_global_rank = 0
             self.multi_gpu_cfg = None
