@@ -1,0 +1,199 @@
+// Input producers of the hot path that the reference runs in eager torch every step:
+//   * ContactSensor.update -> _update_buffers_impl: force history shift + air/contact-time bookkeeping
+//     (reference isaaclab/sensors/contact_sensor/contact_sensor.py:320-379, sensors/sensor_base.py:196-205,287-297)
+//   * CommandManager.compute / UniformVelocityCommand (isaaclab/managers/command_manager.py:122-187,
+//     isaaclab/envs/mdp/commands/velocity_command.py:111-160): metrics, resampling timer, uniform resampling,
+//     heading P-controller (wrap_to_pi), standing envs.
+#include "imx_internal.h"
+
+// ------------------------------------------------------------------------------------------------- contact sensor
+// lane = (env, body).  SensorBase.update: timestamp += dt; outdated |= timestamp - last_update + 1e-6 >= update_period;
+// outdated envs run _update_buffers_impl with elapsed = timestamp - last_update, then last_update = timestamp.
+__global__ void __launch_bounds__(256)
+k_contact_update(int64_t N, int B, int H, const float* __restrict__ new_forces, float dt, float update_period,
+                 float force_threshold, int track_air_time, float* __restrict__ timestamp,
+                 float* __restrict__ timestamp_last, uint8_t* __restrict__ is_outdated, float* __restrict__ net_forces,
+                 float* __restrict__ history, float* __restrict__ last_air, float* __restrict__ cur_air,
+                 float* __restrict__ last_contact, float* __restrict__ cur_contact) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * B) return;
+    const int64_t e = i / B;
+    const int b = (int)(i - e * B);
+    const float ts = timestamp[e] + dt;  // every lane of an env computes the same value; body 0 stores it
+    const float tl = timestamp_last[e];
+    const bool outdated = (is_outdated[e] != 0) || (ts - tl + 1.0e-6f >= update_period);
+    if (outdated) {
+        const float fx = new_forces[i * 3], fy = new_forces[i * 3 + 1], fz = new_forces[i * 3 + 2];
+        net_forces[i * 3] = fx; net_forces[i * 3 + 1] = fy; net_forces[i * 3 + 2] = fz;
+        if (history && H > 0) {  // history[:, 1:] = history[:, :-1]; history[:, 0] = net_forces
+            for (int h = H - 1; h >= 1; --h) {
+                float* dst = history + (((size_t)e * H + h) * B + b) * 3;
+                const float* src = history + (((size_t)e * H + h - 1) * B + b) * 3;
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+            }
+            float* d0 = history + ((size_t)e * H * B + b) * 3;
+            d0[0] = fx; d0[1] = fy; d0[2] = fz;
+        }
+        if (track_air_time) {
+            const float elapsed = ts - tl;
+            const bool is_contact = norm3(fx, fy, fz) > force_threshold;
+            const float ca = cur_air[i], cc = cur_contact[i];
+            const bool first_contact = (ca > 0.0f) && is_contact;
+            const bool first_detached = (cc > 0.0f) && !is_contact;
+            if (first_contact) last_air[i] = ca + elapsed;
+            cur_air[i] = !is_contact ? ca + elapsed : 0.0f;
+            if (first_detached) last_contact[i] = cc + elapsed;
+            cur_contact[i] = is_contact ? cc + elapsed : 0.0f;
+        }
+    }
+}
+
+// second pass (the per-env scalars may only change once every body lane has read them)
+__global__ void k_contact_stamp(int64_t N, float dt, float update_period, float* __restrict__ timestamp,
+                                float* __restrict__ timestamp_last, uint8_t* __restrict__ is_outdated) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const float ts = timestamp[e] + dt;
+    const bool outdated = (is_outdated[e] != 0) || (ts - timestamp_last[e] + 1.0e-6f >= update_period);
+    timestamp[e] = ts;
+    if (outdated) {
+        timestamp_last[e] = ts;
+        is_outdated[e] = 0;
+    }
+}
+
+extern "C" int imx_contact_sensor_update(int64_t N, int64_t B, int64_t H, const float* new_net_forces_d, float dt,
+                                         float update_period, float force_threshold, int track_air_time,
+                                         float* timestamp_d, float* timestamp_last_update_d, uint8_t* is_outdated_d,
+                                         float* net_forces_w_d, float* net_forces_w_history_d, float* last_air_time_d,
+                                         float* current_air_time_d, float* last_contact_time_d,
+                                         float* current_contact_time_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && B > 0 && H >= 0, "imx_contact_sensor_update: bad sizes");
+    IMX_REQUIRE(new_net_forces_d && timestamp_d && timestamp_last_update_d && is_outdated_d && net_forces_w_d,
+                "imx_contact_sensor_update: null argument");
+    IMX_REQUIRE(H == 0 || net_forces_w_history_d, "imx_contact_sensor_update: history buffer missing");
+    IMX_REQUIRE(!track_air_time || (last_air_time_d && current_air_time_d && last_contact_time_d && current_contact_time_d),
+                "imx_contact_sensor_update: air-time buffers missing");
+    const int64_t n = N * B;
+    hipLaunchKernelGGL(k_contact_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, (int)B, (int)H,
+                       new_net_forces_d, dt, update_period, force_threshold, track_air_time, timestamp_d,
+                       timestamp_last_update_d, is_outdated_d, net_forces_w_d, net_forces_w_history_d, last_air_time_d,
+                       current_air_time_d, last_contact_time_d, current_contact_time_d);
+    hipLaunchKernelGGL(k_contact_stamp, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, dt,
+                       update_period, timestamp_d, timestamp_last_update_d, is_outdated_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- velocity command
+// lane = env.  uniforms: (N,7) samples in [0,1) for {time_left, lin_x, lin_y, ang_z, heading, is_heading, is_standing}
+// (parity mode, the reference draws them with Tensor.uniform_ on the CPU generator) or NULL -> counter-based in-kernel.
+struct VelCmdCfg {
+    float resample_lo, resample_hi;
+    float lin_x_lo, lin_x_hi, lin_y_lo, lin_y_hi, ang_z_lo, ang_z_hi, heading_lo, heading_hi;
+    float rel_standing, rel_heading, stiffness;
+    int heading_command;
+    float max_command_step;  // resampling_time_range[1] / step_dt
+};
+
+IMX_DEV float u_at(const float* __restrict__ U, int64_t e, int k, uint64_t seed, uint32_t step) {
+    return U ? U[e * 7 + k] : uniform01(seed + 0x1234567ull * (uint64_t)(k + 1), step, (uint64_t)e);
+}
+
+__global__ void __launch_bounds__(256)
+k_velocity_command(int64_t N, VelCmdCfg c, float dt, const float* __restrict__ quat, const float* __restrict__ lin_w,
+                   const float* __restrict__ ang_w, const uint8_t* __restrict__ reset_mask,
+                   const float* __restrict__ uniforms, uint64_t seed, const int32_t* __restrict__ step_d,
+                   float* __restrict__ cmd, float* __restrict__ heading_target, uint8_t* __restrict__ is_heading,
+                   uint8_t* __restrict__ is_standing, float* __restrict__ time_left, int64_t* __restrict__ counter,
+                   float* __restrict__ metric_xy, float* __restrict__ metric_yaw) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const uint32_t step = step_d ? (uint32_t)step_d[0] : 0u;
+    const float qw = quat[e * 4], qx = quat[e * 4 + 1], qy = quat[e * 4 + 2], qz = quat[e * 4 + 3];
+    float cx = cmd[e * 3], cy = cmd[e * 3 + 1], cz = cmd[e * 3 + 2];
+    float tl = time_left[e];
+    int64_t cnt = counter[e];
+    float mxy = metric_xy[e], myaw = metric_yaw[e];
+    float htgt = heading_target[e];
+    bool head = is_heading[e] != 0, stand = is_standing[e] != 0;
+    bool resample = false;
+    int draw = 0;  // which of the two possible resamplings of this call (reset, timer) -> distinct in-kernel streams
+    if (reset_mask && reset_mask[e]) {  // CommandTerm.reset (command_manager.py:119-147): metrics, counter, resample
+        mxy = 0.0f; myaw = 0.0f; cnt = 0;
+        resample = true;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            // CommandTerm.compute (:149-166): metrics on the current command, timer, resample when it ran out
+            float lbx, lby, lbz, abx, aby, abz;
+            quat_rotate_inverse(qw, qx, qy, qz, lin_w[e * 3], lin_w[e * 3 + 1], lin_w[e * 3 + 2], lbx, lby, lbz);
+            quat_rotate_inverse(qw, qx, qy, qz, ang_w[e * 3], ang_w[e * 3 + 1], ang_w[e * 3 + 2], abx, aby, abz);
+            const float ex = cx - lbx, ey = cy - lby;
+            mxy += sqrtf(ex * ex + ey * ey) / c.max_command_step;  // velocity_command.py:117-123
+            myaw += fabsf(cz - abz) / c.max_command_step;
+            tl -= dt;
+            resample = tl <= 0.0f;
+        }
+        if (resample) {  // CommandTerm._resample (:172-187) + _resample_command (velocity_command.py:125-140)
+            const float* U = uniforms ? uniforms + (size_t)draw * N * 7 : nullptr;
+            const uint64_t sd = seed + 0x9E3779B97F4A7C15ull * (uint64_t)draw;
+            tl = u_at(U, e, 0, sd, step) * (c.resample_hi - c.resample_lo) + c.resample_lo;
+            cnt += 1;
+            cx = u_at(U, e, 1, sd, step) * (c.lin_x_hi - c.lin_x_lo) + c.lin_x_lo;
+            cy = u_at(U, e, 2, sd, step) * (c.lin_y_hi - c.lin_y_lo) + c.lin_y_lo;
+            cz = u_at(U, e, 3, sd, step) * (c.ang_z_hi - c.ang_z_lo) + c.ang_z_lo;
+            if (c.heading_command) {
+                htgt = u_at(U, e, 4, sd, step) * (c.heading_hi - c.heading_lo) + c.heading_lo;
+                head = u_at(U, e, 5, sd, step) <= c.rel_heading;
+            }
+            stand = u_at(U, e, 6, sd, step) <= c.rel_standing;
+            ++draw;
+        }
+        resample = false;
+    }
+    // _update_command (velocity_command.py:142-160)
+    if (c.heading_command && head) {
+        float fx, fy, fz;
+        quat_apply(qw, qx, qy, qz, 1.0f, 0.0f, 0.0f, fx, fy, fz);  // heading_w (articulation_data.py:518-526)
+        const float heading = atan2f(fy, fx);
+        const float err = wrap_to_pi(htgt - heading);
+        cz = fminf(fmaxf(c.stiffness * err, c.ang_z_lo), c.ang_z_hi);
+    }
+    if (stand) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+    cmd[e * 3] = cx; cmd[e * 3 + 1] = cy; cmd[e * 3 + 2] = cz;
+    heading_target[e] = htgt;
+    is_heading[e] = head ? 1 : 0;
+    is_standing[e] = stand ? 1 : 0;
+    time_left[e] = tl;
+    counter[e] = cnt;
+    metric_xy[e] = mxy;
+    metric_yaw[e] = myaw;
+}
+
+extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, const float* root_quat_w_d,
+                                    const float* root_lin_vel_w_d, const float* root_ang_vel_w_d,
+                                    const uint8_t* reset_mask_d, const float* uniforms_d, uint64_t seed,
+                                    const int32_t* step_counter_d, float* vel_command_b_d, float* heading_target_d,
+                                    uint8_t* is_heading_env_d, uint8_t* is_standing_env_d, float* time_left_d,
+                                    int64_t* command_counter_d, float* metric_error_vel_xy_d,
+                                    float* metric_error_vel_yaw_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && cfg15, "imx_velocity_command: bad arguments");
+    IMX_REQUIRE(root_quat_w_d && root_lin_vel_w_d && root_ang_vel_w_d && vel_command_b_d && heading_target_d &&
+                    is_heading_env_d && is_standing_env_d && time_left_d && command_counter_d && metric_error_vel_xy_d &&
+                    metric_error_vel_yaw_d, "imx_velocity_command: null argument");
+    VelCmdCfg c;
+    c.resample_lo = cfg15[0]; c.resample_hi = cfg15[1];
+    c.lin_x_lo = cfg15[2]; c.lin_x_hi = cfg15[3]; c.lin_y_lo = cfg15[4]; c.lin_y_hi = cfg15[5];
+    c.ang_z_lo = cfg15[6]; c.ang_z_hi = cfg15[7]; c.heading_lo = cfg15[8]; c.heading_hi = cfg15[9];
+    c.rel_standing = cfg15[10]; c.rel_heading = cfg15[11]; c.stiffness = cfg15[12];
+    c.max_command_step = cfg15[13];
+    c.heading_command = heading_command;
+    IMX_REQUIRE(c.max_command_step > 0.0f, "imx_velocity_command: max_command_step must be positive");
+    hipLaunchKernelGGL(k_velocity_command, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, c, dt,
+                       root_quat_w_d, root_lin_vel_w_d, root_ang_vel_w_d, reset_mask_d, uniforms_d, seed, step_counter_d,
+                       vel_command_b_d, heading_target_d, is_heading_env_d, is_standing_env_d, time_left_d,
+                       command_counter_d, metric_error_vel_xy_d, metric_error_vel_yaw_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

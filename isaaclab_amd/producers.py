@@ -1,0 +1,123 @@
+"""Host-side mirrors of the reference's per-step input producers, running on libimx:
+
+* :class:`ContactSensorState` -- ``ContactSensor`` data buffers + ``update(dt)`` (reference
+  isaaclab/sensors/contact_sensor/contact_sensor.py:140-210,320-379; isaaclab/sensors/sensor_base.py:182-205,287-297)
+* :class:`UniformVelocityCommand` -- ``CommandTerm.reset/compute`` + the uniform velocity command
+  (isaaclab/managers/command_manager.py:119-187; isaaclab/envs/mdp/commands/velocity_command.py:37-160)
+
+Attribute names follow the reference so that term functions reading ``sensor.data.*`` / ``command_manager`` keep working.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import types
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+class ContactSensorState:
+    def __init__(self, num_envs: int, num_bodies: int, history_length: int = 0, track_air_time: bool = False,
+                 update_period: float = 0.0, force_threshold: float = 1.0, device="cuda:0"):
+        N, B, H = num_envs, num_bodies, history_length
+        self.num_envs, self.num_bodies, self.history_length = N, B, H
+        self.cfg = types.SimpleNamespace(track_air_time=track_air_time, update_period=update_period,
+                                         force_threshold=force_threshold, history_length=H)
+        dev = torch.device(device)
+        self.device = dev
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        self._timestamp, self._timestamp_last_update = z(N), z(N)
+        self._is_outdated = torch.ones(N, dtype=torch.bool, device=dev)  # sensor_base.py:_initialize_impl
+        d = types.SimpleNamespace()
+        d.net_forces_w = z(N, B, 3)
+        d.net_forces_w_history = z(N, max(H, 1), B, 3)
+        d.last_air_time, d.current_air_time = z(N, B), z(N, B)
+        d.last_contact_time, d.current_contact_time = z(N, B), z(N, B)
+        self.data = d
+
+    def update(self, new_net_forces_w: torch.Tensor, dt: float):
+        """``SensorBase.update(dt)`` with PhysX's ``get_net_contact_forces`` result passed in as ``(N,B,3)``."""
+        d = self.data
+        f = new_net_forces_w.reshape(self.num_envs, self.num_bodies, 3).contiguous()
+        H = self.history_length
+        check(lib().imx_contact_sensor_update(
+            self.num_envs, self.num_bodies, H, f.data_ptr(), float(dt), float(self.cfg.update_period),
+            float(self.cfg.force_threshold), int(self.cfg.track_air_time), self._timestamp.data_ptr(),
+            self._timestamp_last_update.data_ptr(), self._is_outdated.data_ptr(), d.net_forces_w.data_ptr(),
+            d.net_forces_w_history.data_ptr() if H > 0 else None, d.last_air_time.data_ptr(), d.current_air_time.data_ptr(),
+            d.last_contact_time.data_ptr(), d.current_contact_time.data_ptr(), _lib.current_stream(self.device)))
+        if H == 0:  # contact_sensor.py:302: history is a view of the current forces
+            d.net_forces_w_history = d.net_forces_w.unsqueeze(1)
+
+    def reset(self, env_ids=None):
+        """contact_sensor.py:143-165 + sensor_base.py:182-194"""
+        ids = slice(None) if env_ids is None else env_ids
+        self._timestamp[ids] = 0.0
+        self._timestamp_last_update[ids] = 0.0
+        self._is_outdated[ids] = True
+        d = self.data
+        d.net_forces_w[ids] = 0.0
+        d.net_forces_w_history[ids] = 0.0
+        if self.cfg.track_air_time:
+            d.current_air_time[ids] = 0.0
+            d.last_air_time[ids] = 0.0
+            d.current_contact_time[ids] = 0.0
+            d.last_contact_time[ids] = 0.0
+
+    def compute_first_contact(self, dt: float, abs_tol: float = 1.0e-8) -> torch.Tensor:
+        """contact_sensor.py:176-210"""
+        if not self.cfg.track_air_time:
+            raise RuntimeError("The contact sensor is not configured to track contact time."
+                               "Please enable the 'track_air_time' in the sensor configuration.")
+        c = self.data.current_contact_time
+        return (c > 0.0) * (c < (dt + abs_tol))
+
+
+class UniformVelocityCommand:
+    """``cfg``: dict / object with the fields of ``UniformVelocityCommandCfg`` (velocity_command_cfg.py)."""
+
+    def __init__(self, cfg, num_envs: int, step_dt: float, device="cuda:0", seed: int = 0):
+        get = (lambda k, d=None: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))
+        rng = get("ranges")
+        rget = (lambda k: rng.get(k)) if isinstance(rng, dict) else (lambda k: getattr(rng, k))
+        self.heading_command = bool(get("heading_command", False))
+        heading = rget("heading")
+        if self.heading_command and heading is None:
+            raise ValueError("The velocity command has heading commands active (heading_command=True) but the "
+                             "`ranges.heading` parameter is set to None.")
+        heading = heading or (0.0, 0.0)
+        rt = get("resampling_time_range")
+        self._cfg15 = np.asarray([rt[0], rt[1], *rget("lin_vel_x"), *rget("lin_vel_y"), *rget("ang_vel_z"), *heading,
+                                  get("rel_standing_envs", 0.0), get("rel_heading_envs", 1.0),
+                                  get("heading_control_stiffness", 1.0), rt[1] / step_dt, 0.0], dtype=np.float32)
+        N = num_envs
+        dev = torch.device(device)
+        self.num_envs, self.device, self.seed = N, dev, int(seed)
+        self.vel_command_b = torch.zeros(N, 3, device=dev)
+        self.heading_target = torch.zeros(N, device=dev)
+        self.is_heading_env = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.is_standing_env = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.time_left = torch.zeros(N, device=dev)
+        self.command_counter = torch.zeros(N, dtype=torch.long, device=dev)
+        self.metrics = {"error_vel_xy": torch.zeros(N, device=dev), "error_vel_yaw": torch.zeros(N, device=dev)}
+        self._step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    @property
+    def command(self) -> torch.Tensor:
+        return self.vel_command_b
+
+    def compute(self, dt: float, root_quat_w, root_lin_vel_w, root_ang_vel_w, reset_mask=None, uniforms=None):
+        """``reset(ids of reset_mask)`` then ``compute(dt)``; ``uniforms``: optional (2,N,7) parity samples."""
+        self._step += 1
+        check(lib().imx_velocity_command(
+            self.num_envs, self._cfg15.ctypes.data, int(self.heading_command), float(dt), root_quat_w.data_ptr(),
+            root_lin_vel_w.data_ptr(), root_ang_vel_w.data_ptr(), _lib.ptr(reset_mask), _lib.ptr(uniforms), self.seed,
+            self._step.data_ptr(), self.vel_command_b.data_ptr(), self.heading_target.data_ptr(),
+            self.is_heading_env.data_ptr(), self.is_standing_env.data_ptr(), self.time_left.data_ptr(),
+            self.command_counter.data_ptr(), self.metrics["error_vel_xy"].data_ptr(),
+            self.metrics["error_vel_yaw"].data_ptr(), _lib.current_stream(self.device)))
+        return self.vel_command_b

@@ -1,0 +1,107 @@
+"""SURVEY 8f row 1 (ContactSensor update, UniformVelocityCommand): oracle vs the fixtures produced by the real reference
+classes (CPU), HIP vs the same fixtures (GPU)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN, assert_close
+
+Z = np.load(os.path.join(GOLDEN, "producers.npz"))
+
+
+def t(key):
+    return torch.from_numpy(np.ascontiguousarray(Z[key]))
+
+
+CONTACT_KEYS = ("net_forces_w", "net_forces_w_history", "last_air_time", "current_air_time", "last_contact_time",
+                "current_contact_time")
+CMD_KEYS = ("vel_command_b", "heading_target", "is_heading_env", "is_standing_env", "time_left", "command_counter")
+
+
+def test_contact_sensor_oracle_matches_reference():
+    from oracle.producers_oracle import contact_sensor_update
+
+    m = json.loads(str(Z["contact/meta"]))
+    N, B, H = m["N"], m["B"], m["H"]
+    st = dict(timestamp=torch.zeros(N), timestamp_last_update=torch.zeros(N), is_outdated=torch.ones(N, dtype=torch.bool),
+              net_forces_w=torch.zeros(N, B, 3), net_forces_w_history=torch.zeros(N, H, B, 3), last_air_time=torch.zeros(N, B),
+              current_air_time=torch.zeros(N, B), last_contact_time=torch.zeros(N, B), current_contact_time=torch.zeros(N, B))
+    forces = t("contact/forces")
+    for k in range(m["steps"]):
+        if k == m["reset_step"]:
+            ids = torch.tensor(m["reset_ids"])
+            for name in ("timestamp", "timestamp_last_update", "net_forces_w", "net_forces_w_history", "current_air_time",
+                         "last_air_time", "current_contact_time", "last_contact_time"):  # contact_sensor.py:143-170
+                st[name][ids] = 0.0
+            st["is_outdated"][ids] = True
+        contact_sensor_update(st, forces[k], m["dt"], m["update_period"], m["force_threshold"], H, True)
+        for name in CONTACT_KEYS:
+            assert torch.equal(st[name], t(f"contact/step{k}/{name}")), (k, name)
+        assert torch.equal(st["timestamp"], t(f"contact/step{k}/timestamp"))
+
+
+def test_velocity_command_oracle_matches_reference():
+    from oracle.producers_oracle import VelocityCommandOracle
+
+    m = json.loads(str(Z["command/meta"]))
+    orc = VelocityCommandOracle(m["cfg"], m["N"], m["step_dt"])
+    for k in range(m["steps"]):
+        tag = f"command/step{k}"
+        orc.reset_and_compute(m["step_dt"], t(f"{tag}/root_quat_w"), t(f"{tag}/root_lin_vel_w"), t(f"{tag}/root_ang_vel_w"),
+                              t(f"{tag}/reset_mask"), t(f"{tag}/uniforms"))
+        for name in CMD_KEYS:
+            got = getattr(orc, name)
+            ref = t(f"{tag}/{name}")
+            if got.dtype in (torch.bool, torch.long):
+                assert torch.equal(got, ref), (k, name)
+            else:
+                assert_close(got, ref, 1e-6, f"step {k} {name}")
+        assert_close(orc.metrics["error_vel_xy"], t(f"{tag}/error_vel_xy"), 1e-6, "error_vel_xy")
+        assert_close(orc.metrics["error_vel_yaw"], t(f"{tag}/error_vel_yaw"), 1e-6, "error_vel_yaw")
+
+
+@pytest.mark.gpu
+def test_contact_sensor_hip_matches_reference():
+    from isaaclab_amd.producers import ContactSensorState
+
+    m = json.loads(str(Z["contact/meta"]))
+    s = ContactSensorState(m["N"], m["B"], m["H"], True, m["update_period"], m["force_threshold"], "cuda:0")
+    forces = t("contact/forces").cuda()
+    for k in range(m["steps"]):
+        if k == m["reset_step"]:
+            s.reset(torch.tensor(m["reset_ids"], device="cuda"))
+        s.update(forces[k], m["dt"])
+        for name in CONTACT_KEYS:
+            assert torch.equal(getattr(s.data, name).cpu(), t(f"contact/step{k}/{name}")), (k, name)
+        assert torch.equal(s._timestamp.cpu(), t(f"contact/step{k}/timestamp"))
+        assert torch.equal(s._timestamp_last_update.cpu(), t(f"contact/step{k}/timestamp_last_update"))
+        assert torch.equal(s.compute_first_contact(0.02).cpu(), t(f"contact/step{k}/first_contact"))
+
+
+@pytest.mark.gpu
+def test_velocity_command_hip_matches_reference():
+    from isaaclab_amd.producers import UniformVelocityCommand
+
+    m = json.loads(str(Z["command/meta"]))
+    cmd = UniformVelocityCommand(m["cfg"], m["N"], m["step_dt"], "cuda:0")
+    for k in range(m["steps"]):
+        tag = f"command/step{k}"
+        cmd.compute(m["step_dt"], t(f"{tag}/root_quat_w").cuda(), t(f"{tag}/root_lin_vel_w").cuda(),
+                    t(f"{tag}/root_ang_vel_w").cuda(), t(f"{tag}/reset_mask").cuda(), t(f"{tag}/uniforms").cuda())
+        for name in CMD_KEYS:
+            got, ref = getattr(cmd, name).cpu(), t(f"{tag}/{name}")
+            if ref.dtype in (torch.bool, torch.long):
+                assert torch.equal(got, ref), (k, name)
+            else:
+                assert_close(got, ref, 1e-5, f"step {k} {name}")
+        assert_close(cmd.metrics["error_vel_xy"], t(f"{tag}/error_vel_xy"), 1e-5, "error_vel_xy")
+        assert_close(cmd.metrics["error_vel_yaw"], t(f"{tag}/error_vel_yaw"), 1e-5, "error_vel_yaw")
+    # in-kernel generator: ranges respected, standing envs zeroed
+    cmd.compute(m["step_dt"], t("command/step0/root_quat_w").cuda(), t("command/step0/root_lin_vel_w").cuda(),
+                t("command/step0/root_ang_vel_w").cuda(), torch.ones(m["N"], dtype=torch.bool, device="cuda"), None)
+    c = cmd.command.cpu()
+    assert float(c.abs().max()) <= 1.0 + 1e-6 and bool((c[cmd.is_standing_env.cpu()] == 0).all())
