@@ -300,13 +300,15 @@ int imx_contact_sensor_update(int64_t N, int64_t B, int64_t H, const float* new_
                               float* net_forces_w_history_d, float* last_air_time_d, float* current_air_time_d,
                               float* last_contact_time_d, float* current_contact_time_d, imx_stream_t stream);
 
-/* CommandTerm.reset (for envs flagged in reset_mask_d, may be NULL) followed by CommandTerm.compute(dt) of
+/* CommandTerm.reset (for envs flagged in reset_mask_d, may be NULL) followed -- when do_compute != 0 -- by
+ * CommandTerm.compute(dt) of
  * UniformVelocityCommand (managers/command_manager.py:119-187, envs/mdp/commands/velocity_command.py:111-160).
  * cfg15 (HOST floats) = {resampling_time lo,hi, lin_vel_x lo,hi, lin_vel_y lo,hi, ang_vel_z lo,hi, heading lo,hi,
  * rel_standing_envs, rel_heading_envs, heading_control_stiffness, resampling_time_range[1]/step_dt, -}.
  * uniforms_d: optional (2,N,7) samples in [0,1) {time_left, lin_x, lin_y, ang_z, heading, is_heading, is_standing} for
  * the first / second resampling of an env within this call (parity mode); NULL -> counter-based in-kernel generator. */
-int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, const float* root_quat_w_d,
+int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, int do_compute,
+                         const float* root_quat_w_d,
                          const float* root_lin_vel_w_d, const float* root_ang_vel_w_d, const uint8_t* reset_mask_d,
                          const float* uniforms_d, uint64_t seed, const int32_t* step_counter_d, float* vel_command_b_d,
                          float* heading_target_d, uint8_t* is_heading_env_d, uint8_t* is_standing_env_d,

@@ -74,7 +74,7 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_contact_sensor_update": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_float, c_float, c_float, c_int] + [c_void_p] * 9
                                   + [c_void_p]),
-    "imx_velocity_command": (c_int, [c_int64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "imx_velocity_command": (c_int, [c_int64, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_uint64, c_void_p] + [c_void_p] * 8 + [c_void_p]),
 }
 

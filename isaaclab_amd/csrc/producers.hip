@@ -101,7 +101,7 @@ IMX_DEV float u_at(const float* __restrict__ U, int64_t e, int k, uint64_t seed,
 }
 
 __global__ void __launch_bounds__(256)
-k_velocity_command(int64_t N, VelCmdCfg c, float dt, const float* __restrict__ quat, const float* __restrict__ lin_w,
+k_velocity_command(int64_t N, VelCmdCfg c, float dt, int do_compute, const float* __restrict__ quat, const float* __restrict__ lin_w,
                    const float* __restrict__ ang_w, const uint8_t* __restrict__ reset_mask,
                    const float* __restrict__ uniforms, uint64_t seed, const int32_t* __restrict__ step_d,
                    float* __restrict__ cmd, float* __restrict__ heading_target, uint8_t* __restrict__ is_heading,
@@ -123,7 +123,7 @@ k_velocity_command(int64_t N, VelCmdCfg c, float dt, const float* __restrict__ q
         mxy = 0.0f; myaw = 0.0f; cnt = 0;
         resample = true;
     }
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (do_compute ? 2 : 1); ++pass) {
         if (pass == 1) {
             // CommandTerm.compute (:149-166): metrics on the current command, timer, resample when it ran out
             float lbx, lby, lbz, abx, aby, abz;
@@ -153,14 +153,14 @@ k_velocity_command(int64_t N, VelCmdCfg c, float dt, const float* __restrict__ q
         resample = false;
     }
     // _update_command (velocity_command.py:142-160)
-    if (c.heading_command && head) {
+    if (do_compute && c.heading_command && head) {
         float fx, fy, fz;
         quat_apply(qw, qx, qy, qz, 1.0f, 0.0f, 0.0f, fx, fy, fz);  // heading_w (articulation_data.py:518-526)
         const float heading = atan2f(fy, fx);
         const float err = wrap_to_pi(htgt - heading);
         cz = fminf(fmaxf(c.stiffness * err, c.ang_z_lo), c.ang_z_hi);
     }
-    if (stand) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
+    if (do_compute && stand) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
     cmd[e * 3] = cx; cmd[e * 3 + 1] = cy; cmd[e * 3 + 2] = cz;
     heading_target[e] = htgt;
     is_heading[e] = head ? 1 : 0;
@@ -171,7 +171,8 @@ k_velocity_command(int64_t N, VelCmdCfg c, float dt, const float* __restrict__ q
     metric_yaw[e] = myaw;
 }
 
-extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, const float* root_quat_w_d,
+extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, int do_compute,
+                                    const float* root_quat_w_d,
                                     const float* root_lin_vel_w_d, const float* root_ang_vel_w_d,
                                     const uint8_t* reset_mask_d, const float* uniforms_d, uint64_t seed,
                                     const int32_t* step_counter_d, float* vel_command_b_d, float* heading_target_d,
@@ -191,7 +192,7 @@ extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_c
     c.heading_command = heading_command;
     IMX_REQUIRE(c.max_command_step > 0.0f, "imx_velocity_command: max_command_step must be positive");
     hipLaunchKernelGGL(k_velocity_command, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, c, dt,
-                       root_quat_w_d, root_lin_vel_w_d, root_ang_vel_w_d, reset_mask_d, uniforms_d, seed, step_counter_d,
+                       do_compute, root_quat_w_d, root_lin_vel_w_d, root_ang_vel_w_d, reset_mask_d, uniforms_d, seed, step_counter_d,
                        vel_command_b_d, heading_target_d, is_heading_env_d, is_standing_env_d, time_left_d,
                        command_counter_d, metric_error_vel_xy_d, metric_error_vel_yaw_d);
     IMX_HIP(hipGetLastError());

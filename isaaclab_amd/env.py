@@ -277,6 +277,8 @@ class CommandManager:
         self._env = env
 
     def get_command(self, name: str) -> torch.Tensor:
+        if self._env.command_term is not None:
+            return self._env.command_term.command
         return self._env.feed["command"]
 
     def compute(self, dt: float):
@@ -359,7 +361,7 @@ class ManagerBasedRLEnv:
     def __init__(self, cfg: Any, render_mode: str | None = None, *, state_feed: StateFeed | None = None,
                  robot: RobotSpec | str | None = None, terrain=None, num_envs: int | None = None,
                  device: str | torch.device | None = None, seed: int | None = None, noise_seed: int = 0,
-                 terrain_cell: float = 0.0, **kwargs):
+                 terrain_cell: float = 0.0, use_command_term: bool = False, use_contact_sensor: bool = False, **kwargs):
         if isinstance(cfg, str):
             cfg = load_task_cfg(cfg)
         self.cfg = cfg
@@ -461,6 +463,25 @@ class ManagerBasedRLEnv:
         self.reward_manager = RewardManager(self)
         self.termination_manager = TerminationManager(self)
         self.command_manager = CommandManager(self)
+        # -- optional producers run by the env itself instead of arriving through the feed
+        self.command_term = None
+        if use_command_term:
+            from .producers import UniformVelocityCommand
+
+            cmds = (env_dict.get("commands") or {})
+            if not cmds:
+                raise ValueError("use_command_term=True but the env cfg has no command terms")
+            self.command_term = UniformVelocityCommand(next(iter(cmds.values())), N, plan.step_dt, self.device, seed=noise_seed)
+        self.contact_sensor = None
+        if use_contact_sensor:
+            from .producers import ContactSensorState
+
+            cs = env_dict["scene"].get("contact_forces")
+            if cs is None:
+                raise ValueError("use_contact_sensor=True but the scene has no contact_forces sensor")
+            self.contact_sensor = ContactSensorState(N, plan.num_bodies, int(cs.get("history_length", 0)),
+                                                     bool(cs.get("track_air_time", False)), float(cs.get("update_period", 0.0)),
+                                                     float(cs.get("force_threshold", 1.0)), self.device)
         self.scene = _Scene(self)
         self._ext_funcs = {
             "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None and t.weight != 0.0],
@@ -521,6 +542,12 @@ class ManagerBasedRLEnv:
         if st is None:
             snap = self.feed.snapshot(idx)
             kw = {n: snap[n].data_ptr() for n in _lib.STATE_FIELDS if n in snap}
+            if self.command_term is not None:
+                kw["command"] = self.command_term.vel_command_b.data_ptr()
+            if self.contact_sensor is not None:
+                d = self.contact_sensor.data
+                kw.update(net_forces_w_history=d.net_forces_w_history.data_ptr(), last_air_time=d.last_air_time.data_ptr(),
+                          current_air_time=d.current_air_time.data_ptr(), current_contact_time=d.current_contact_time.data_ptr())
             kw["ext_reward"] = _lib.ptr(self._ext_reward)
             kw["ext_term"] = _lib.ptr(self._ext_term)
             kw["ext_obs"] = _lib.ptr(self._ext_obs)
@@ -585,6 +612,14 @@ class ManagerBasedRLEnv:
         self.action_manager.reset(ids)
         self._episode_length_buf[ids] = 0
         self.extras["log"] = log
+        f = self.feed
+        if self.contact_sensor is not None:
+            self.contact_sensor.reset(None if env_ids is None else env_ids)
+        if self.command_term is not None:  # CommandTerm.reset: resample, no compute (manager_based_rl_env.py:379-380)
+            mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+            mask[ids] = True
+            self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], mask,
+                                      do_compute=False)
         obs = self._compute_observations()
         return {"policy": obs}, self.extras
 
@@ -595,6 +630,9 @@ class ManagerBasedRLEnv:
         # -- physics (decimation x sim.step) is replaced by the feed moving to its next recorded state
         self._sim_step_counter += int(self.cfg_decimation)
         self.feed.advance()
+        if self.contact_sensor is not None:
+            # scene.update -> ContactSensor.update: the feed delivers one force sample per env step (history slot 0)
+            self.contact_sensor.update(self.feed["net_forces_w_history"][:, 0], self.step_dt)
         self.common_step_counter += 1
         # -- post-physics: counters, terminations, rewards, reset bookkeeping (one kernel)
         if self._ext_funcs["rew"] or self._ext_funcs["term"]:
@@ -603,7 +641,10 @@ class ManagerBasedRLEnv:
         check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
                                                  ctypes.byref(self._bufs), _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
-        # -- commands / interval events: supplied by the feed
+        # -- commands: CommandTerm.reset for the reset envs + CommandManager.compute(dt) (one kernel), or from the feed
+        if self.command_term is not None:
+            f = self.feed
+            self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], self.reset_buf)
         # -- observations on the post-reset state (one kernel, ray-cast fused)
         obs = self._compute_observations()
         return {"policy": obs}, self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras

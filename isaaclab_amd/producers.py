@@ -110,11 +110,12 @@ class UniformVelocityCommand:
     def command(self) -> torch.Tensor:
         return self.vel_command_b
 
-    def compute(self, dt: float, root_quat_w, root_lin_vel_w, root_ang_vel_w, reset_mask=None, uniforms=None):
-        """``reset(ids of reset_mask)`` then ``compute(dt)``; ``uniforms``: optional (2,N,7) parity samples."""
+    def compute(self, dt: float, root_quat_w, root_lin_vel_w, root_ang_vel_w, reset_mask=None, uniforms=None,
+                do_compute: bool = True):
+        """``reset(ids of reset_mask)`` then (``do_compute``) ``compute(dt)``; ``uniforms``: optional (2,N,7) parity samples."""
         self._step += 1
         check(lib().imx_velocity_command(
-            self.num_envs, self._cfg15.ctypes.data, int(self.heading_command), float(dt), root_quat_w.data_ptr(),
+            self.num_envs, self._cfg15.ctypes.data, int(self.heading_command), float(dt), int(do_compute), root_quat_w.data_ptr(),
             root_lin_vel_w.data_ptr(), root_ang_vel_w.data_ptr(), _lib.ptr(reset_mask), _lib.ptr(uniforms), self.seed,
             self._step.data_ptr(), self.vel_command_b.data_ptr(), self.heading_target.data_ptr(),
             self.is_heading_env.data_ptr(), self.is_standing_env.data_ptr(), self.time_left.data_ptr(),

@@ -174,3 +174,36 @@ def test_in_kernel_noise_is_uniform_and_bounded():
     assert float(d[:, 0:3].abs().max()) <= 0.1 + 1e-6 and float(d[:, 0:3].abs().max()) > 0.05
     assert float(d[:, 9:12].abs().max()) == 0.0
     assert abs(float(d[:, 24:36].mean())) < 0.2  # joint_vel noise U(-1.5,1.5), 768 samples
+
+
+def test_env_owned_command_term_and_contact_sensor():
+    """SURVEY 8f row 1 wired into the env: commands are resampled by imx_velocity_command (reset envs + timer) and the
+    contact sensor state is advanced by imx_contact_sensor_update from the feed's per-step forces."""
+    from isaaclab_amd.env import ManagerBasedRLEnv
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), use_command_term=True, use_contact_sensor=True)
+    obs, _ = env.reset()
+    cmd0 = env.command_manager.get_command("base_velocity").clone()
+    assert float(cmd0.abs().max()) <= 1.0 and float(cmd0.abs().sum()) > 0  # resampled at reset inside the cfg ranges
+    assert torch.equal(obs["policy"][:, 9:12], cmd0)  # velocity_commands columns (no noise on this term)
+    assert int(env.command_term.command_counter.min()) == 1
+    a = torch.zeros(64, 12, device="cuda:0")
+    env.episode_length_buf = torch.full((64,), 998)
+    for k in range(3):
+        counter_before = env.command_term.command_counter.clone()
+        obs, rew, term, tout, _ = env.step(a)
+        c = env.command_manager.get_command("base_velocity")
+        assert torch.equal(obs["policy"][:, 9:12], c)
+        stand = env.command_term.is_standing_env
+        assert bool((c[stand] == 0).all()) and float(c.abs().max()) <= 1.0 + 1e-6
+        if k == 1:  # 998 + 2 steps = the 1000-step limit: every env times out and gets a fresh command (counter -> 1)
+            assert bool(tout.all())
+            assert torch.equal(env.command_term.command_counter, torch.ones(64, dtype=torch.long, device="cuda:0"))
+        else:
+            assert not bool(tout.any()) and torch.equal(env.command_term.command_counter[~term], counter_before[~term])
+    cs = env.contact_sensor
+    assert torch.equal(cs.data.net_forces_w_history[:, 0], env.feed["net_forces_w_history"][:, 0])
+    assert float(cs._timestamp.max()) == pytest.approx(3 * env.step_dt, rel=1e-5)
+    assert torch.isfinite(rew).all()
+    env.close()
