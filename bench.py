@@ -47,7 +47,7 @@ def obs_kernel_bytes_per_env(plan) -> float:
     return float(reads + mesh + writes)
 
 
-def build_env(task, num_envs, device, seed, snapshots, terrain_tiles):
+def build_env(task, num_envs, device, seed, snapshots, terrain_tiles, mesh=None):
     from isaaclab_amd.env import ManagerBasedRLEnv, load_task_cfg
     from isaaclab_amd.robots import ROBOTS
     from isaaclab_amd.state_feed import StateFeed
@@ -58,8 +58,11 @@ def build_env(task, num_envs, device, seed, snapshots, terrain_tiles):
     terrain = ext = None
     ntri = 0
     if fx["env"]["scene"].get("height_scanner") is not None:
-        v, t, e = make_rough_terrain(terrain_tiles[0], terrain_tiles[1], tile=8.0, horizontal_scale=0.1, border=20.0, seed=0)
-        terrain, ext, ntri = (v, t), (e[0] - 1.0, e[1] - 1.0), len(t)
+        if mesh is not None:  # reuse an uploaded TerrainMesh (same tiles -> same extent)
+            terrain, ext, ntri = mesh, (0.5 * terrain_tiles[0] * 8.0 - 1.0, 0.5 * terrain_tiles[1] * 8.0 - 1.0), mesh.num_triangles
+        else:
+            v, t, e = make_rough_terrain(terrain_tiles[0], terrain_tiles[1], tile=8.0, horizontal_scale=0.1, border=20.0, seed=0)
+            terrain, ext, ntri = (v, t), (e[0] - 1.0, e[1] - 1.0), len(t)
     feed = StateFeed(robot, num_envs, device, seed=seed, num_snapshots=snapshots, extent_xy=ext)
     env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed)
     return fx, env, ntri
@@ -266,6 +269,20 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_obs<false> (observation assembly + fused height-scanner ray-cast)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
+        # the same kernel at 16x the batch (65 536 envs): what the layout reaches once launch latency is amortised
+        if os.environ.get("IMX_BENCH_LARGE_N", "1") == "1" and args.task == TASK:
+            try:
+                big_n = 65536
+                _, env_big, _ = build_env(args.task, big_n, device, 7, 1, tuple(args.terrain_tiles), mesh=env.terrain)
+                env_big.reset()
+                kb = time_obs_kernel(env_big, launches=50)
+                out["roofline_large_n"] = {"num_envs": big_n, "kernel": out["roofline"]["kernel"], "avg_launch_us": kb * 1e6,
+                                           "achieved": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9,
+                                           "frac": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9 / HBM_PEAK_GBS,
+                                           "unit": "GB/s"}
+                del env_big
+            except Exception as exc:  # secondary measurement only
+                out["roofline_large_n"] = {"error": str(exc)}
         out["ppo"] = {k: round(v, 6) for k, v in stats.items()}
         out["ppo"]["learning_rate"] = runner.alg.learning_rate
         if world == 1 and not args.no_cpu_baseline:
