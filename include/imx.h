@@ -315,6 +315,21 @@ int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, flo
                          float* time_left_d, int64_t* command_counter_d, float* metric_error_vel_xy_d,
                          float* metric_error_vel_yaw_d, imx_stream_t stream);
 
+/* ArticulationData.root_state_w + joint_acc (assets/articulation/articulation_data.py:365-380,546-556): split PhysX's
+ * root transforms (N,7: pos, quat XYZW) / velocities (N,6) into root_pos_w, root_quat_w (WXYZ, convert_quat
+ * utils/math.py:177-222), root_lin_vel_w, root_ang_vel_w; joint_acc = (dof_vel - previous)/time_elapsed, previous <-
+ * dof_vel (pass joint_acc_d = NULL to skip).  SURVEY 8f row 4. */
+int imx_articulation_update(int64_t N, int64_t J, const float* root_transforms_xyzw_d, const float* root_velocities_d,
+                            const float* dof_velocities_d, float time_elapsed, float* root_pos_w_d, float* root_quat_w_d,
+                            float* root_lin_vel_w_d, float* root_ang_vel_w_d, float* previous_joint_vel_d,
+                            float* joint_acc_d, imx_stream_t stream);
+
+/* rsl_rl EmpiricalNormalization.forward (3rd party v2.3.1, absent): if update != 0 fold the batch (N,D) into the running
+ * mean / variance (count, mean, var, std are device buffers; Chan's update with the biased batch variance), then
+ * out = (x - mean) / (std + eps).  PARITY UNPINNED.  SURVEY 8f row 3. */
+int imx_empirical_normalization(int64_t N, int64_t D, const float* x_d, int update, float eps, float* mean_d, float* var_d,
+                                float* std_d, float* count_d, float* out_d, imx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,8 @@ _SIGNATURES = {
                                   + [c_void_p]),
     "imx_velocity_command": (c_int, [c_int64, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_uint64, c_void_p] + [c_void_p] * 8 + [c_void_p]),
+    "imx_articulation_update": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float] + [c_void_p] * 6 + [c_void_p]),
+    "imx_empirical_normalization": (c_int, [c_int64, c_int64, c_void_p, c_int, c_float] + [c_void_p] * 5 + [c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -198,3 +198,116 @@ extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_c
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- articulation data
+// ArticulationData.root_state_w (reference isaaclab/assets/articulation/articulation_data.py:365-380): PhysX root
+// transforms are (pos, quat XYZW) -> convert_quat(to="wxyz") (utils/math.py:177-222) and root velocities (lin, ang);
+// ArticulationData.joint_acc (:546-556): finite difference (joint_vel - previous_joint_vel) / elapsed, previous <- current.
+// One launch: lanes [0, N) split the root state, all lanes stride over the N*J joint entries.
+__global__ void __launch_bounds__(256)
+k_articulation_update(int64_t N, int J, const float* __restrict__ root_tf, const float* __restrict__ root_vel,
+                      const float* __restrict__ dof_vel, float elapsed, float* __restrict__ pos, float* __restrict__ quat,
+                      float* __restrict__ lin, float* __restrict__ ang, float* __restrict__ prev_vel,
+                      float* __restrict__ joint_acc) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = tid; e < N; e += nth) {
+        const float* t = root_tf + e * 7;
+        pos[e * 3] = t[0]; pos[e * 3 + 1] = t[1]; pos[e * 3 + 2] = t[2];
+        quat[e * 4] = t[6]; quat[e * 4 + 1] = t[3]; quat[e * 4 + 2] = t[4]; quat[e * 4 + 3] = t[5];  // xyzw -> wxyz
+        const float* v = root_vel + e * 6;
+        lin[e * 3] = v[0]; lin[e * 3 + 1] = v[1]; lin[e * 3 + 2] = v[2];
+        ang[e * 3] = v[3]; ang[e * 3 + 1] = v[4]; ang[e * 3 + 2] = v[5];
+    }
+    if (joint_acc) {
+        const int64_t n = N * J;
+        for (int64_t i = tid; i < n; i += nth) {
+            const float v = dof_vel[i];
+            joint_acc[i] = (v - prev_vel[i]) / elapsed;
+            prev_vel[i] = v;
+        }
+    }
+}
+
+extern "C" int imx_articulation_update(int64_t N, int64_t J, const float* root_transforms_xyzw_d,
+                                       const float* root_velocities_d, const float* dof_velocities_d, float time_elapsed,
+                                       float* root_pos_w_d, float* root_quat_w_d, float* root_lin_vel_w_d,
+                                       float* root_ang_vel_w_d, float* previous_joint_vel_d, float* joint_acc_d,
+                                       imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && J >= 0, "imx_articulation_update: bad sizes");
+    IMX_REQUIRE(root_transforms_xyzw_d && root_velocities_d && root_pos_w_d && root_quat_w_d && root_lin_vel_w_d &&
+                    root_ang_vel_w_d, "imx_articulation_update: null argument");
+    IMX_REQUIRE(!joint_acc_d || (dof_velocities_d && previous_joint_vel_d && J > 0 && time_elapsed > 0.0f),
+                "imx_articulation_update: joint_acc needs dof velocities, the previous velocities and a positive elapsed time");
+    const int64_t n = std::max<int64_t>(N, joint_acc_d ? N * J : 0);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_articulation_update, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, (int)J, root_transforms_xyzw_d,
+                       root_velocities_d, dof_velocities_d, time_elapsed, root_pos_w_d, root_quat_w_d, root_lin_vel_w_d,
+                       root_ang_vel_w_d, previous_joint_vel_d, joint_acc_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- empirical normalization
+// rsl_rl EmpiricalNormalization (upstream rsl_rl/modules/normalizer.py @ v2.3.1; enabled by
+// RslRlOnPolicyRunnerCfg.empirical_normalization, reference isaaclab_rl/rsl_rl/rl_cfg.py): running mean / variance
+// of the observations (Chan's parallel update with the batch mean / biased variance), then (x - mean) / (std + eps).
+// PARITY UNPINNED (rsl_rl absent).  One block per 64 columns: column-wise batch moments, fixed-order merge.
+__global__ void __launch_bounds__(256)
+k_norm_update(int64_t N, int D, const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ var,
+              float* __restrict__ stdv, float* __restrict__ count_d, int update_count) {
+    __shared__ float s_sum[4][64], s_sq[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rgrp = threadIdx.x >> 6;
+    float bm = 0.0f, bv = 0.0f;
+    // two-pass batch moments (mean, then biased variance), rows strided over the 4 waves
+    float s = 0.0f;
+    if (c < D)
+        for (int64_t r = rgrp; r < N; r += 4) s += x[r * D + c];
+    s_sum[rgrp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (c < D) bm = ((s_sum[0][threadIdx.x & 63] + s_sum[1][threadIdx.x & 63]) + (s_sum[2][threadIdx.x & 63] + s_sum[3][threadIdx.x & 63])) / (float)N;
+    float q = 0.0f;
+    if (c < D)
+        for (int64_t r = rgrp; r < N; r += 4) { const float d = x[r * D + c] - bm; q += d * d; }
+    s_sq[rgrp][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rgrp == 0 && c < D) {
+        bv = ((s_sq[0][threadIdx.x] + s_sq[1][threadIdx.x]) + (s_sq[2][threadIdx.x] + s_sq[3][threadIdx.x])) / (float)N;
+        const float cnt = count_d[0];
+        const float rate = (float)N / (cnt + (float)N);
+        const float delta = bm - mean[c];
+        const float m_new = mean[c] + rate * delta;
+        const float v_new = var[c] + rate * (bv - var[c] + delta * (bm - m_new));
+        mean[c] = m_new;
+        var[c] = v_new;
+        stdv[c] = sqrtf(v_new);
+    }
+    (void)update_count;
+}
+__global__ void k_norm_count(int64_t N, float* __restrict__ count_d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) count_d[0] += (float)N;
+}
+__global__ void __launch_bounds__(256)
+k_norm_apply(int64_t n, int D, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ stdv,
+             float eps, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        out[i] = (x[i] - mean[c]) / (stdv[c] + eps);
+    }
+}
+
+extern "C" int imx_empirical_normalization(int64_t N, int64_t D, const float* x_d, int update, float eps, float* mean_d,
+                                           float* var_d, float* std_d, float* count_d, float* out_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && D > 0 && x_d && mean_d && var_d && std_d && count_d && out_d, "imx_empirical_normalization: bad arguments");
+    if (update) {
+        hipLaunchKernelGGL(k_norm_update, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, (hipStream_t)stream, N, (int)D, x_d,
+                           mean_d, var_d, std_d, count_d, 1);
+        hipLaunchKernelGGL(k_norm_count, dim3(1), dim3(64), 0, (hipStream_t)stream, N, count_d);
+    }
+    const int64_t n = N * D;
+    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       n, (int)D, x_d, mean_d, std_d, eps, out_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

@@ -122,3 +122,39 @@ class UniformVelocityCommand:
             self.command_counter.data_ptr(), self.metrics["error_vel_xy"].data_ptr(),
             self.metrics["error_vel_yaw"].data_ptr(), _lib.current_stream(self.device)))
         return self.vel_command_b
+
+
+class ArticulationRootState:
+    """``ArticulationData`` root state + ``joint_acc`` from PhysX-layout tensors (reference
+    isaaclab/assets/articulation/articulation_data.py:365-380,546-556), SURVEY 8f row 4.
+
+    ``update(root_transforms (N,7 pos+quat XYZW), root_velocities (N,6), dof_velocities (N,J), dt)`` fills
+    ``root_pos_w, root_quat_w (WXYZ), root_lin_vel_w, root_ang_vel_w, joint_vel, joint_acc``.
+    """
+
+    def __init__(self, num_envs: int, num_joints: int, device="cuda:0", initial_joint_vel: torch.Tensor | None = None):
+        N, J = num_envs, num_joints
+        dev = torch.device(device)
+        self.num_envs, self.num_joints, self.device = N, J, dev
+        self.root_pos_w = torch.zeros(N, 3, device=dev)
+        self.root_quat_w = torch.zeros(N, 4, device=dev)
+        self.root_lin_vel_w = torch.zeros(N, 3, device=dev)
+        self.root_ang_vel_w = torch.zeros(N, 3, device=dev)
+        self.joint_acc = torch.zeros(N, J, device=dev)
+        self._previous_joint_vel = torch.zeros(N, J, device=dev) if initial_joint_vel is None else initial_joint_vel.clone()
+        self.joint_vel = self._previous_joint_vel
+        # TimestampedBuffer semantics (isaaclab/utils/buffers/timestamped_buffer.py): buffers start at timestamp -1.0, so
+        # the reference's first finite difference divides by (dt + 1.0) -- reproduced, not "fixed"
+        self._sim_timestamp = 0.0
+        self._joint_acc_timestamp = -1.0
+
+    def update(self, root_transforms, root_velocities, dof_velocities, dt: float):
+        self._sim_timestamp += dt
+        elapsed = self._sim_timestamp - self._joint_acc_timestamp
+        self._joint_acc_timestamp = self._sim_timestamp
+        check(lib().imx_articulation_update(
+            self.num_envs, self.num_joints, root_transforms.data_ptr(), root_velocities.data_ptr(), dof_velocities.data_ptr(),
+            float(elapsed), self.root_pos_w.data_ptr(), self.root_quat_w.data_ptr(), self.root_lin_vel_w.data_ptr(),
+            self.root_ang_vel_w.data_ptr(), self._previous_joint_vel.data_ptr(), self.joint_acc.data_ptr(),
+            _lib.current_stream(self.device)))
+        self.joint_vel = dof_velocities

@@ -157,10 +157,51 @@ def command_golden(rec):
     rec["command/meta"] = np.array(json.dumps(dict(N=N, steps=steps, step_dt=step_dt, cfg=keep), default=list))
 
 
+def articulation_golden(rec):
+    """Real ArticulationData over a fake PhysX view (root transforms in XYZW, velocities, dof velocities)."""
+    import isaaclab.assets.articulation.articulation_data as ad_mod
+
+    N, J, steps, dt = 32, 12, 4, 0.005
+    g = torch.Generator().manual_seed(17)
+    cur = {}
+    class View:  # weak-referenceable stand-in for physx.ArticulationView
+        count = N
+        get_root_transforms = staticmethod(lambda: cur["tf"])
+        get_root_velocities = staticmethod(lambda: cur["vel"])
+        get_dof_velocities = staticmethod(lambda: cur["dv"])
+        get_dof_positions = staticmethod(lambda: cur["dv"])
+
+    view = View()
+    ad_mod.SimulationManager = types.SimpleNamespace(
+        get_physics_sim_view=lambda: types.SimpleNamespace(get_gravity=lambda: (0.0, 0.0, -9.81)))
+    cur["dv"] = torch.randn(N, J, generator=g)
+    cur["tf"] = torch.zeros(N, 7)
+    cur["vel"] = torch.zeros(N, 6)
+    rec["artic/initial_joint_vel"] = cur["dv"].numpy().copy()
+    data = ArticulationData(view, "cpu")
+    for t in range(steps):
+        q = torch.randn(N, 4, generator=g)
+        q = q / q.norm(dim=-1, keepdim=True)
+        cur["tf"] = torch.cat([torch.randn(N, 3, generator=g), q], dim=-1)  # PhysX: quat is XYZW
+        cur["vel"] = torch.randn(N, 6, generator=g)
+        cur["dv"] = torch.randn(N, J, generator=g)
+        data.update(dt)
+        tag = f"artic/step{t}"
+        rec[f"{tag}/root_transforms"], rec[f"{tag}/root_velocities"], rec[f"{tag}/dof_velocities"] = (
+            cur["tf"].numpy().copy(), cur["vel"].numpy().copy(), cur["dv"].numpy().copy())
+        rec[f"{tag}/root_pos_w"] = data.root_pos_w.numpy().copy()
+        rec[f"{tag}/root_quat_w"] = data.root_quat_w.numpy().copy()
+        rec[f"{tag}/root_lin_vel_w"] = data.root_lin_vel_w.numpy().copy()
+        rec[f"{tag}/root_ang_vel_w"] = data.root_ang_vel_w.numpy().copy()
+        rec[f"{tag}/joint_acc"] = data.joint_acc.numpy().copy()
+    rec["artic/meta"] = np.array(json.dumps(dict(N=N, J=J, steps=steps, dt=dt)))
+
+
 def main():
     rec = {}
     contact_sensor_golden(rec)
     command_golden(rec)
+    articulation_golden(rec)
     np.savez_compressed(os.path.join(GOLDEN, "producers.npz"), **rec)
     print("[golden] producers:", len(rec), "arrays")
 

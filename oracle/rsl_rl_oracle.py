@@ -75,3 +75,27 @@ def adaptive_lr(lr: float, kl_mean: float, desired_kl: float) -> float:
     if kl_mean < desired_kl / 2.0 and kl_mean > 0.0:
         return min(1e-2, lr * 1.5)
     return lr
+
+
+class EmpiricalNormalizationOracle:
+    """rsl_rl/modules/normalizer.py::EmpiricalNormalization (v2.3.1): running mean/var with the biased batch variance."""
+
+    def __init__(self, dim: int, eps: float = 1e-2):
+        self.eps = eps
+        self.mean = torch.zeros(1, dim)
+        self.var = torch.ones(1, dim)
+        self.std = torch.ones(1, dim)
+        self.count = 0
+
+    def forward(self, x, training: bool = True):
+        if training:
+            count_x = x.shape[0]
+            self.count += count_x
+            rate = count_x / self.count
+            var_x = torch.var(x, dim=0, unbiased=False, keepdim=True)
+            mean_x = torch.mean(x, dim=0, keepdim=True)
+            delta_mean = mean_x - self.mean
+            self.mean = self.mean + rate * delta_mean
+            self.var = self.var + rate * (var_x - self.var + delta_mean * (mean_x - self.mean))
+            self.std = torch.sqrt(self.var)
+        return (x - self.mean) / (self.std + self.eps)

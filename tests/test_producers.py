@@ -105,3 +105,59 @@ def test_velocity_command_hip_matches_reference():
                 t("command/step0/root_ang_vel_w").cuda(), torch.ones(m["N"], dtype=torch.bool, device="cuda"), None)
     c = cmd.command.cpu()
     assert float(c.abs().max()) <= 1.0 + 1e-6 and bool((c[cmd.is_standing_env.cpu()] == 0).all())
+
+
+def test_articulation_oracle_matches_reference():
+    from oracle.mdp_oracle import convert_quat
+
+    m = json.loads(str(Z["artic/meta"]))
+    prev = t("artic/initial_joint_vel").clone()
+    sim_t, acc_t = 0.0, -1.0  # TimestampedBuffer starts at -1.0: the first difference divides by dt + 1.0
+    for k in range(m["steps"]):
+        tag = f"artic/step{k}"
+        sim_t += m["dt"]
+        elapsed, acc_t = sim_t - acc_t, sim_t
+        tf, vel, dv = t(f"{tag}/root_transforms"), t(f"{tag}/root_velocities"), t(f"{tag}/dof_velocities")
+        # articulation_data.py:365-380, 546-556
+        assert torch.equal(tf[:, :3], t(f"{tag}/root_pos_w"))
+        assert torch.equal(convert_quat(tf[:, 3:7], to="wxyz"), t(f"{tag}/root_quat_w"))
+        assert torch.equal(vel[:, :3], t(f"{tag}/root_lin_vel_w")) and torch.equal(vel[:, 3:], t(f"{tag}/root_ang_vel_w"))
+        assert_close((dv - prev) / elapsed, t(f"{tag}/joint_acc"), 1e-6, "joint_acc")
+        prev = dv.clone()
+
+
+@pytest.mark.gpu
+def test_articulation_hip_matches_reference():
+    from isaaclab_amd.producers import ArticulationRootState
+
+    m = json.loads(str(Z["artic/meta"]))
+    st = ArticulationRootState(m["N"], m["J"], "cuda:0", t("artic/initial_joint_vel").cuda())
+    for k in range(m["steps"]):
+        tag = f"artic/step{k}"
+        st.update(t(f"{tag}/root_transforms").cuda(), t(f"{tag}/root_velocities").cuda(), t(f"{tag}/dof_velocities").cuda(), m["dt"])
+        for name in ("root_pos_w", "root_quat_w", "root_lin_vel_w", "root_ang_vel_w"):
+            assert torch.equal(getattr(st, name).cpu(), t(f"{tag}/{name}")), (k, name)
+        assert_close(st.joint_acc, t(f"{tag}/joint_acc"), 1e-5, "joint_acc")
+
+
+@pytest.mark.gpu
+def test_empirical_normalization_matches_rsl_rl_restatement():
+    from isaaclab_amd.rsl_rl.normalizer import EmpiricalNormalization
+    from oracle.rsl_rl_oracle import EmpiricalNormalizationOracle
+
+    D = 235
+    norm = EmpiricalNormalization([D]).cuda()
+    orc = EmpiricalNormalizationOracle(D)
+    g = torch.Generator().manual_seed(5)
+    for k in range(4):
+        x = torch.randn(4096 if k else 64, D, generator=g) * (1 + k) + 0.3 * k
+        got = norm(x.cuda())
+        ref = orc.forward(x, training=True)
+        assert_close(got, ref, 1e-5, f"normalised obs, batch {k}")
+        assert_close(norm._mean, orc.mean, 1e-5, "mean") and assert_close(norm._var, orc.var, 1e-5, "var") is None
+    assert norm.count == orc.count
+    norm.eval()
+    x = torch.randn(10, D, generator=g)
+    m0 = norm._mean.clone()
+    assert_close(norm(x.cuda()), orc.forward(x, training=False), 1e-5, "eval mode")
+    assert torch.equal(norm._mean, m0)
