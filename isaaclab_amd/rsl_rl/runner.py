@@ -40,10 +40,15 @@ class OnPolicyRunner:
         self.alg = PPO(policy, device=self.device, multi_gpu_cfg=self.multi_gpu_cfg, **self.alg_cfg)
         self.num_steps_per_env = int(train_cfg["num_steps_per_env"])
         self.save_interval = int(train_cfg.get("save_interval", 50))
-        if train_cfg.get("empirical_normalization", False):
-            raise NotImplementedError("EmpiricalNormalization is a SURVEY 8f 'next' row (policy side)")
-        self.obs_normalizer = torch.nn.Identity().to(self.device)
-        self.privileged_obs_normalizer = torch.nn.Identity().to(self.device)
+        self.empirical_normalization = bool(train_cfg.get("empirical_normalization", False))
+        if self.empirical_normalization:
+            from .normalizer import EmpiricalNormalization
+
+            self.obs_normalizer = EmpiricalNormalization(shape=[num_obs], until=int(1.0e8)).to(self.device)
+            self.privileged_obs_normalizer = EmpiricalNormalization(shape=[num_privileged_obs], until=int(1.0e8)).to(self.device)
+        else:
+            self.obs_normalizer = torch.nn.Identity().to(self.device)
+            self.privileged_obs_normalizer = torch.nn.Identity().to(self.device)
         self.alg.init_storage("rl", self.env.num_envs, self.num_steps_per_env, [num_obs], [num_privileged_obs],
                               [self.env.num_actions])
         self.disable_logs = self.is_distributed and self.gpu_global_rank != 0
@@ -88,7 +93,7 @@ class OnPolicyRunner:
 
         return (isinstance(self.env, RslRlVecEnvWrapper) and isinstance(self.env.unwrapped, ManagerBasedRLEnv)
                 and self.privileged_obs_type is None and self.alg.policy.noise_std_type == "scalar"
-                and self.device.type == "cuda")
+                and self.device.type == "cuda" and not self.empirical_normalization)
 
     def _rollout(self):
         if self._fusable():
@@ -97,6 +102,7 @@ class OnPolicyRunner:
         for _ in range(self.num_steps_per_env):
             actions = self.alg.act(obs, obs)
             obs, rewards, dones, infos = self.env.step(actions)
+            obs = self.obs_normalizer(obs)  # upstream: normalise right after env.step (the first obs stays raw)
             self.alg.process_env_step(rewards, dones, infos)
             # episode book-keeping on the device (upstream pulls finished episodes to the host every step)
             self._cur_reward_sum += rewards
@@ -238,9 +244,15 @@ class OnPolicyRunner:
 
     def train_mode(self):
         self.alg.policy.train()
+        if self.empirical_normalization:
+            self.obs_normalizer.train()
+            self.privileged_obs_normalizer.train()
 
     def eval_mode(self):
         self.alg.policy.eval()
+        if self.empirical_normalization:
+            self.obs_normalizer.eval()
+            self.privileged_obs_normalizer.eval()
 
     def add_git_repo_to_log(self, repo_file_path):
         pass

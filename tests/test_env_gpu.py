@@ -207,3 +207,36 @@ def test_env_owned_command_term_and_contact_sensor():
     assert float(cs._timestamp.max()) == pytest.approx(3 * env.step_dt, rel=1e-5)
     assert torch.isfinite(rew).all()
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["fused-eager", "fused-graph", "generic-normalized"])
+def test_runner_learn_modes(mode, tmp_path):
+    """OnPolicyRunner.learn through the three rollout paths (train.py:167-183 surface), checkpoint round trip."""
+    from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    feed = g.feed("cuda:0")  # 4 snapshots
+    from isaaclab_amd.env import ManagerBasedRLEnv
+
+    env = RslRlVecEnvWrapper(ManagerBasedRLEnv(g.fixture, state_feed=feed))
+    cfg = dict(g.fixture["agent"], num_steps_per_env=8, empirical_normalization=(mode == "generic-normalized"))
+    runner = OnPolicyRunner(env, cfg, log_dir=str(tmp_path), device="cuda:0", use_graph=(mode == "fused-graph"))
+    assert runner._fusable() == (mode != "generic-normalized")
+    p0 = runner.alg.bucket.flat.clone()
+    runner.learn(2, init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    s = runner.alg.loss_dict()
+    assert all(np.isfinite(v) for v in s.values()), s
+    assert not torch.equal(p0, runner.alg.bucket.flat)  # parameters moved
+    assert runner.alg.storage.observations.abs().sum() > 0 and runner.current_learning_iteration == 2
+    assert int(runner.alg._adam[1]) == 2 * 5 * 4  # Adam steps = iterations x epochs x minibatches
+    ck = str(tmp_path / "model.pt")
+    runner.save(ck)
+    before = runner.alg.bucket.flat.clone()
+    runner.alg.bucket.flat.zero_()
+    runner.load(ck)
+    assert torch.equal(before, runner.alg.bucket.flat)
+    policy = runner.get_inference_policy(device="cuda:0")
+    a = policy(env.get_observations()[0])
+    assert a.shape == (64, 12) and torch.isfinite(a).all()
+    assert hasattr(runner.alg.policy, "actor") and hasattr(runner.alg.policy, "critic") and not runner.alg.policy.is_recurrent
