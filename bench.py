@@ -225,12 +225,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
     t0 = time.perf_counter()
-    tc = 0.0
-    for _ in range(args.steps):
-        c0 = time.perf_counter()
-        iteration()
-        tc += time.perf_counter() - c0
+    for k in range(args.steps):  # same work as iteration(), with three device-side event records (no host syncs)
+        ev[3 * k].record()
+        runner.collect()
+        with torch.inference_mode():
+            runner.alg.compute_returns(runner.last_obs)
+        ev[3 * k + 1].record()
+        runner.alg.update()
+        ev[3 * k + 2].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -241,6 +245,8 @@ def main():
         elapsed = float(tt.item())
     value = args.num_envs * T * world * args.steps / elapsed
     stats = runner.alg.loss_dict()
+    collect_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)) / args.steps
+    update_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)) / args.steps
 
     # --- secondary measurements on rank 0 (outside the timed region)
     out = {
@@ -254,6 +260,7 @@ def main():
                                f"terrain {ntri} triangles, {args.snapshots} state snapshots resident in HBM",
                    "parallelism": f"dp{world}", "rollout": "eager" if args.no_graph else "hipGraph",
                    "policy_params": runner.alg.bucket.numel},
+        "phase_ms": {"collect_plus_gae": collect_ms, "update": update_ms},
     }
     if rank == 0:
         env_rate, env_step_s = time_env_path(env, T, iters=20)

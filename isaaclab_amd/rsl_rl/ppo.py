@@ -186,6 +186,8 @@ class PPO:
         self._actor_layers = _mlp_layers(self.policy.actor)
         self._critic_layers = _mlp_layers(self.policy.critic)
         self._ws: dict = {}
+        self._side = None
+        self.two_streams = kwargs.get("two_streams", True)
 
     @property
     def learning_rate(self) -> float:
@@ -231,6 +233,13 @@ class PPO:
         allreduce_mean_(self.bucket.grad, self.gpu_world_size)
 
     # ---- update ----------------------------------------------------------------------------------------------------
+    def _side_stream(self):
+        if not self.two_streams or self.device.type != "cuda":
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
     def _workspace(self, M: int, A: int):
         ws = self._ws.get((M, A))
         if ws is None:
@@ -247,8 +256,20 @@ class PPO:
         stream = _lib.current_stream(self.device)
         M, A = actions.shape
         ws = self._workspace(M, A)
-        mu, saved_a = mlp_forward(self._actor_layers, obs)
-        value, saved_c = mlp_forward(self._critic_layers, critic_obs)
+        # actor and critic are independent until the loss: run the critic on a side stream so that the narrow layers
+        # (N = 128, 12, 1 columns: fewer tiles than CUs) of one network overlap with the other's
+        side = self._side_stream()
+        main = torch.cuda.current_stream(self.device)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                value, saved_c = mlp_forward(self._critic_layers, critic_obs)
+            mu, saved_a = mlp_forward(self._actor_layers, obs)
+            main.wait_stream(side)
+            value.record_stream(main)  # allocated on the side stream, consumed by the loss kernels on the main stream
+        else:
+            mu, saved_a = mlp_forward(self._actor_layers, obs)
+            value, saved_c = mlp_forward(self._critic_layers, critic_obs)
         if pol.noise_std_type == "scalar":
             sigma, sstride = pol.std, 0
         else:
@@ -267,8 +288,15 @@ class PPO:
             torch.sum(ws["dsigma"], dim=0, out=pol.std.grad)
         else:
             torch.sum(ws["dsigma"] * sigma, dim=0, out=pol.log_std.grad)
-        mlp_backward(self._actor_layers, saved_a, ws["dmu"])
-        mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"])
+            main.wait_stream(side)
+        else:
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"])
+            mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
         self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
         return self._out8
 

@@ -133,8 +133,18 @@ class OnPolicyRunner:
         bootstrap = 0 if env.is_finite_horizon else 1
         obs = self._obs
         for t in range(self.num_steps_per_env):
-            mu, _ = mlp_forward(alg._actor_layers, obs)
-            value, _ = mlp_forward(alg._critic_layers, obs)
+            side = alg._side_stream()
+            if side is not None:  # critic beside the actor (fork/join is capturable: both streams join the graph)
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    value, _ = mlp_forward(alg._critic_layers, obs)
+                mu, _ = mlp_forward(alg._actor_layers, obs)
+                main.wait_stream(side)
+                value.record_stream(main)
+            else:
+                mu, _ = mlp_forward(alg._actor_layers, obs)
+                value, _ = mlp_forward(alg._critic_layers, obs)
             check(L.imx_policy_act(N, A, D, mu.data_ptr(), pol.std.data_ptr(), value.data_ptr(), obs.data_ptr(),
                                    self._act_seed, step_ptr, st.actions[t].data_ptr(), st.actions_log_prob[t].data_ptr(),
                                    st.mu[t].data_ptr(), st.sigma[t].data_ptr(), st.values[t].data_ptr(),
