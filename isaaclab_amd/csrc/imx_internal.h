@@ -61,24 +61,31 @@ PlanView imx_plan_view(const imx_plan* p);
 
 // ---- mesh ---------------------------------------------------------------------------------------------------------
 // Cells of the xy grid are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height scanner maps
-// to a handful of contiguous runs.  One int32 descriptor per cell:
+// to a handful of contiguous runs.  One 16-byte descriptor per cell {meta, id0, id1, zrest}; meta:
 //   kind = desc & 3:  0 empty
 //                     1 LATTICE  the cell holds exactly the two triangles (a,b,c),(a,d,b) of one height-field quad
 //                                (convert_height_field_to_mesh topology); face ids = desc>>2 and +1; its corners sit in
 //                                the tile's 9x9 vertex pool: slot (py*9+px) = a, +1 = d, +9 = c, +10 = b.  A vertex is
 //                                stored once per tile and shared by the up to four cells around it (16 B / vertex).
-//                     2 GENERAL  count = (desc>>2)&63 triangle references starting at record desc>>8; one 48-byte record
-//                                per reference: ax ay az bx | by bz cx cy | cz face(int) 0 0
+//                     2 GENERAL  count = (desc>>2)&63 (even) references starting at refs[desc>>8]; a reference is
+//                                {triangle id, zrest}: sorted by descending triangle top (max z), zrest = highest top
+//                                among the references after it (a downward ray stops once its hit is above zrest).
+//                                The first pair (id0, id1, zrest after it) is repeated in the descriptor, so an
+//                                interior cell of a box top needs descriptor -> two records and nothing else.
+//                                Triangle records (48 B, ONE per triangle, shared by all the cells that reference it --
+//                                a box face covering hundreds of cells stays hot in L2):
+//                                ax ay az bx | by bz cx cy | cz face(int) ztop 0
 //                     3 GENERAL_IND  the same through gtab[desc>>2] = {first record, count} (first >= 2^24 or count > 63)
 #define IMX_CELL_EMPTY 0
 #define IMX_CELL_LATTICE 1
 #define IMX_CELL_GENERAL 2
 #define IMX_CELL_GENERAL_IND 3
 struct MeshView {
-    const int32_t* cell_desc;  // (ntx*nty*64)
+    const int4* cell_desc;     // (ntx*nty*64) {meta, id0, id1, zrest after the first pair}
     const float4* tile_pool;   // (ntx*nty*81) xyz0
-    const int2* gtab;          // (general cells)
-    const float4* tri_rec;     // (general references, 3 x float4)
+    const int2* gtab;          // (general cells with out-of-range inline fields)
+    const int4* refs;          // (general references / 2) pairs {id0, zrest0, id1, zrest1}
+    const float4* tri_rec;     // (F, 3 x float4)
     int ntx, nty;
     int nx, ny;
     float x0, y0, cell, inv_cell;
@@ -90,7 +97,8 @@ struct imx_mesh {
     float* d_tile_pool = nullptr;
     int32_t* d_gtab = nullptr;
     float* d_tri_rec = nullptr;
-    int64_t num_refs = 0;  // general triangle records
+    int32_t* d_refs = nullptr;
+    int64_t num_refs = 0;  // general cell references
     int32_t max_refs = 0;
     int64_t n_lattice = 0, n_general = 0;
 };

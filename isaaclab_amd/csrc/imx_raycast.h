@@ -100,7 +100,7 @@ IMX_DEV void test_tri(const WoopRay& r, float4 a, float4 b, float4 c, int32_t f,
 IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int32_t d = m.cell_desc[c];
+    const int32_t d = m.cell_desc[c].x;
     const int kind = d & 3;
     if (kind == IMX_CELL_LATTICE) {
         const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
@@ -111,9 +111,12 @@ IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, floa
     } else if (kind != IMX_CELL_EMPTY) {
         int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
         if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
-        for (int k = g.x; k < g.x + g.y; ++k) {
-            const float4* q = m.tri_rec + (size_t)k * 3;
-            test_record(r, q[0], q[1], q[2], best, face);
+        for (int k = g.x; k < g.x + g.y; k += 2) {
+            const int4 rr = m.refs[k >> 1];
+            const float4* q0 = m.tri_rec + (size_t)rr.x * 3;
+            const float4* q1 = m.tri_rec + (size_t)rr.z * 3;
+            test_record(r, q0[0], q0[1], q0[2], best, face);
+            test_record(r, q1[0], q1[1], q1[2], best, face);
         }
     }
 }
@@ -156,35 +159,48 @@ IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_,
     }
 }
 
-IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz,
+IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
                            float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    // The pool address does not depend on the descriptor: issue all five loads together (one memory round trip for
-    // the common LATTICE case; the pool exists for every tile, so the speculative corner loads are always in bounds)
-    const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
-    const int32_t d = m.cell_desc[c];
-    const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
+    const int4 d4 = m.cell_desc[c];
+    const int32_t d = d4.x;
     const int kind = d & 3;
-    if (kind == IMX_CELL_LATTICE) {  // the common case on a height-field terrain: descriptor + 4 shared corners
+    if (kind == IMX_CELL_LATTICE) {  // height-field quad: descriptor -> 4 shared corners of the tile's vertex pool
+        const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
+        const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
         const int32_t f0 = (int32_t)((uint32_t)d >> 2);
         vertical_tri(va.x, va.y, va.z, vb.x, vb.y, vb.z, vc.x, vc.y, vc.z, f0, ox, oy, oz, flip, Sz, best, face);
         vertical_tri(va.x, va.y, va.z, vd.x, vd.y, vd.z, vb.x, vb.y, vb.z, f0 + 1, ox, oy, oz, flip, Sz, best, face);
     } else if (kind != IMX_CELL_EMPTY) {
-        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
-        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
-        // two records per trip: their six 16-byte loads are independent and issue back to back; an odd tail repeats the
-        // last record (closest-hit is idempotent)
-        const int end = g.x + g.y;
-        for (int k = g.x; k < end; k += 2) {
-            const float4* p = m.tri_rec + (size_t)k * 3;
-            const float4* p2 = m.tri_rec + (size_t)min(k + 1, end - 1) * 3;
+        // first pair straight from the descriptor: descriptor -> two shared triangle records (six 16-byte loads)
+        {
+            const float4* p = m.tri_rec + (size_t)d4.y * 3;
+            const float4* p2 = m.tri_rec + (size_t)d4.z * 3;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2];
             const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
             vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
                          best, face);
             vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
                          best, face);
+            // references are sorted by descending top; d4.w = highest top among those after this pair.  A downward
+            // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
+            if (flip && face >= 0 && __int_as_float(d4.w) < oz + best * dz) return;
+        }
+        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
+        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
+        const int end = g.x + g.y;
+        for (int k = g.x + 2; k < end; k += 2) {  // the rest of the list: one 16-byte load gives the next two ids
+            const int4 rr = m.refs[k >> 1];
+            const float4* p = m.tri_rec + (size_t)rr.x * 3;
+            const float4* p2 = m.tri_rec + (size_t)rr.z * 3;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
+            vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
+                         best, face);
+            vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
+                         best, face);
+            if (flip && face >= 0 && __int_as_float(rr.w) < oz + best * dz) break;
         }
     }
 }
@@ -198,11 +214,11 @@ IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, 
     int nbx, nby;
     const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
     const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);
-    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, best, face);
+    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, best, face);
     if (nbx | nby) {  // within tau of a cell boundary (rare): the neighbouring cells as well
-        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, best, face);
-        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, best, face);
-        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, best, face);
+        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, best, face);
+        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, best, face);
+        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, best, face);
     }
     if (face < 0) return false;
     t_hit = best;

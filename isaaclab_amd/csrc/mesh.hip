@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 
 #include "imx_internal.h"
@@ -57,6 +58,33 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     // ---- pass 1: per-triangle cell ranges, per-cell reference counts (CSR), ascending triangle ids per cell
     std::vector<int32_t> start((size_t)ncell + 1, 0);
     std::vector<int32_t> ra((size_t)F * 4);
+    // exact pruning inside the bounding-box range: a triangle stays in a cell only if it overlaps the cell grown by tau
+    // (separating-axis test on the three edge normals, grid units, double).  A ray in cell k lies inside the grown cell
+    // of every cell it looks at (its own and the tau-snapped neighbours), so no hit is lost; the diagonal half of a box
+    // top that only touches a cell's bounding box is dropped.  Strips one cell wide (walls, slivers) are kept whole.
+    auto overlaps = [&](int64_t f, int ix, int iy) -> bool {
+        const int32_t* q = &ra[(size_t)f * 4];
+        if (q[0] == q[1] || q[2] == q[3]) return true;
+        double g[3][2];
+        for (int c = 0; c < 3; ++c) {
+            const float* p = verts + 3 * (size_t)tris[3 * f + c];
+            g[c][0] = ((double)p[0] - (double)xmin) * (double)inv_cell;
+            g[c][1] = ((double)p[1] - (double)ymin) * (double)inv_cell;
+        }
+        const double h = 0.5 + 1.1 * (double)IMX_GRID_TAU, cx = ix + 0.5, cy = iy + 0.5;
+        for (int e = 0; e < 3; ++e) {
+            const double* a = g[e];
+            const double* b = g[(e + 1) % 3];
+            const double* o = g[(e + 2) % 3];
+            const double nx_ = -(b[1] - a[1]), ny_ = b[0] - a[0];
+            const double da = nx_ * a[0] + ny_ * a[1], dop = nx_ * o[0] + ny_ * o[1];
+            const double tmin = std::min(da, dop), tmax = std::max(da, dop);
+            const double bc = nx_ * cx + ny_ * cy, br = h * (std::fabs(nx_) + std::fabs(ny_));
+            const double slack = 1e-9 * (std::fabs(bc) + br + std::fabs(tmin) + std::fabs(tmax));
+            if (tmin > bc + br + slack || tmax < bc - br - slack) return false;
+        }
+        return true;
+    };
     for (int64_t f = 0; f < F; ++f) {
         float lox = INFINITY, hix = -INFINITY, loy = INFINITY, hiy = -INFINITY;
         for (int c = 0; c < 3; ++c) {
@@ -69,7 +97,8 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         cell_range(loy, hiy, ymin, inv_cell, (int)ny, ay, by);
         ra[f * 4 + 0] = ax; ra[f * 4 + 1] = bx; ra[f * 4 + 2] = ay; ra[f * 4 + 3] = by;
         for (int iy = ay; iy <= by; ++iy)
-            for (int ix = ax; ix <= bx; ++ix) start[(size_t)imx_cell_index(ix, iy, ntx) + 1]++;
+            for (int ix = ax; ix <= bx; ++ix)
+                if (overlaps(f, ix, iy)) start[(size_t)imx_cell_index(ix, iy, ntx) + 1]++;
     }
     int32_t max_refs = 0;
     for (int64_t c = 0; c < ncell; ++c) {
@@ -83,18 +112,36 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         std::vector<int32_t> cursor(start.begin(), start.end() - 1);
         for (int64_t f = 0; f < F; ++f)
             for (int iy = ra[f * 4 + 2]; iy <= ra[f * 4 + 3]; ++iy)
-                for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix) refs[cursor[(size_t)imx_cell_index(ix, iy, ntx)]++] = (int32_t)f;
+                for (int ix = ra[f * 4 + 0]; ix <= ra[f * 4 + 1]; ++ix)
+                    if (overlaps(f, ix, iy)) refs[cursor[(size_t)imx_cell_index(ix, iy, ntx)]++] = (int32_t)f;
     }
 
     // ---- pass 2: encode every cell.  LATTICE cells (the two triangles of one height-field quad,
     // (a,b,c) + (a,d,b) with consecutive ids, each referenced by this cell only) keep just a descriptor: their four
     // corners live once in the tile's 9x9 vertex pool, shared with the neighbouring cells.  Everything else becomes a
     // GENERAL cell: gtab entry {first record, count} + one 48-byte record per reference.
-    std::vector<int32_t> desc((size_t)ncell, 0);
+    std::vector<int32_t> desc((size_t)ncell * 4, 0);  // int4 per cell: meta, id0, id1, zrest after the first pair
     std::vector<float> pool((size_t)ntile * 81 * 4, 0.0f);
     std::vector<uint8_t> pool_set((size_t)ntile * 81, 0);
     std::vector<int32_t> gtab;
-    std::vector<float> recs;
+    std::vector<int32_t> refl;  // (triangle id, zrest bits) pairs of the general cells
+    std::map<std::vector<int32_t>, uint64_t> dedup;  // reference list -> first index (identical lists are shared)
+    // one 48-byte record per TRIANGLE (shared by every cell that references it): ax ay az bx | by bz cx cy | cz face ztop 0
+    std::vector<float> recs((size_t)F * 12, 0.0f);
+    std::vector<float> ztop((size_t)F);
+    for (int64_t f = 0; f < F; ++f) {
+        float* rec = &recs[(size_t)f * 12];
+        for (int cc = 0; cc < 3; ++cc) memcpy(&rec[cc * 3], verts + 3 * (size_t)tris[3 * (size_t)f + cc], 12);
+        const int32_t fid = (int32_t)f;
+        memcpy(&rec[9], &fid, 4);
+        ztop[f] = std::max(rec[2], std::max(rec[5], rec[8]));
+        rec[10] = ztop[f];
+        // Axis-aligned vertical walls (three equal x or three equal y) sort LAST: a vertical ray can never hit one --
+        // with X the common ray-relative coordinate, U, V, W are fl(b-c), fl(c-a), fl(a-b) of three rounded products
+        // a, b, c (fp32 and the fp64 retry alike), which share a sign only when all three vanish (det == 0) -- so the
+        // downward early exit must not wait for their tops.  The generic DDA path tests the whole list in any order.
+        if ((rec[0] == rec[3] && rec[3] == rec[6]) || (rec[1] == rec[4] && rec[4] == rec[7])) ztop[f] = -INFINITY;
+    }
     int64_t n_lattice = 0, n_general = 0;
     auto single_cell = [&](int32_t f) {
         return ra[(size_t)f * 4] == ra[(size_t)f * 4 + 1] && ra[(size_t)f * 4 + 2] == ra[(size_t)f * 4 + 3];
@@ -125,28 +172,56 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                             memcpy(&pool[s * 4], verts + 3 * (size_t)corner_v[k], 12);
                             pool_set[s] = 1;
                         }
-                        desc[c] = (int32_t)(((uint32_t)r[0] << 2) | IMX_CELL_LATTICE);
+                        desc[(size_t)c * 4] = (int32_t)(((uint32_t)r[0] << 2) | IMX_CELL_LATTICE);
                         lattice = true;
                         ++n_lattice;
                     }
                 }
             }
             if (!lattice) {
-                const uint64_t first = recs.size() / 12;
-                if (first < (1u << 24) && n < 64) {  // first record and count inline: no second table look-up
-                    desc[c] = (int32_t)(((uint32_t)first << 8) | ((uint32_t)n << 2) | IMX_CELL_GENERAL);
+                // references sorted by descending top (max z), ties by triangle id; each carries zrest = the highest top
+                // among the references AFTER it, so a downward ray stops as soon as its hit lies above what is left
+                const int npad = (n + 1) & ~1;
+                std::vector<std::pair<float, int32_t>> order((size_t)n);
+                for (int k = 0; k < n; ++k) order[k] = {ztop[(size_t)r[k]], r[k]};
+                std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+                std::vector<int32_t> key((size_t)npad);
+                for (int k = 0; k < npad; ++k) key[k] = order[std::min(k, n - 1)].second;  // odd counts repeat the last one
+                // identical lists are stored once: every interior cell of a box top / stair tread shares its neighbours' list
+                uint64_t first;
+                auto it = dedup.find(key);
+                if (it != dedup.end()) {
+                    first = it->second;
+                } else {
+                    first = refl.size() / 2;  // in refs (int2 units); always even (16-byte aligned pairs)
+                    dedup.emplace(key, first);
+                    const size_t base = refl.size();
+                    for (int k = 0; k < npad; ++k) {
+                        refl.push_back(key[k]);
+                        refl.push_back(0);
+                    }
+                    float suffix = -INFINITY;
+                    for (int k = npad - 1; k >= 0; --k) {
+                        memcpy(&refl[base + (size_t)k * 2 + 1], &suffix, 4);
+                        if (k < n) suffix = std::max(suffix, order[k].first);
+                    }
+                }
+                // the first pair of references rides in the descriptor itself: an interior cell of a box top / tread needs
+                // descriptor -> two records and nothing else (the same two dependent levels as a lattice cell)
+                desc[(size_t)c * 4 + 1] = key[0];
+                desc[(size_t)c * 4 + 2] = key[1];
+                {
+                    float zr = -INFINITY;
+                    for (int k = 2; k < n; ++k) zr = std::max(zr, order[k].first);
+                    memcpy(&desc[(size_t)c * 4 + 3], &zr, 4);
+                }
+                if (first < (1u << 24) && npad < 64) {  // first ref and count inline: no second table look-up
+                    desc[(size_t)c * 4] = (int32_t)(((uint32_t)first << 8) | ((uint32_t)npad << 2) | IMX_CELL_GENERAL);
                 } else {
                     IMX_REQUIRE(gtab.size() / 2 < (1u << 29), "imx_mesh_create: too many general cells");
-                    desc[c] = (int32_t)(((uint32_t)(gtab.size() / 2) << 2) | IMX_CELL_GENERAL_IND);
+                    desc[(size_t)c * 4] = (int32_t)(((uint32_t)(gtab.size() / 2) << 2) | IMX_CELL_GENERAL_IND);
                     gtab.push_back((int32_t)first);
-                    gtab.push_back(n);
-                }
-                for (int k = 0; k < n; ++k) {
-                    const int32_t f = r[k];
-                    float rec[12] = {0};
-                    for (int cc = 0; cc < 3; ++cc) memcpy(&rec[cc * 3], verts + 3 * (size_t)tris[3 * (size_t)f + cc], 12);
-                    memcpy(&rec[9], &f, 4);
-                    recs.insert(recs.end(), rec, rec + 12);
+                    gtab.push_back(npad);
                 }
                 ++n_general;
             }
@@ -156,7 +231,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         int64_t degenerate = 0, total = 0;
         for (int64_t c = 0; c < ncell; ++c) {
             const int n = start[c + 1] - start[c];
-            if (n == 0 || (desc[c] & 3) == IMX_CELL_LATTICE) continue;
+            if (n == 0 || (desc[(size_t)c * 4] & 3) == IMX_CELL_LATTICE) continue;
             int nv = 0;
             for (int k = 0; k < n; ++k) {
                 const uint32_t* t = tris + 3 * (size_t)refs[start[c] + k];
@@ -173,9 +248,9 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)histv[i]);
         fprintf(stderr, "\n[imx mesh] degenerate (zero xy-area) refs %lld of %lld\n", (long long)degenerate, (long long)total);
     }
-    IMX_REQUIRE(recs.size() / 12 < (1ull << 31), "imx_mesh_create: too many general triangle records");
+    IMX_REQUIRE(refl.size() / 2 < (1ull << 31), "imx_mesh_create: too many general cell references");
     if (gtab.empty()) gtab.assign(2, 0);
-    if (recs.empty()) recs.assign(12, 0.0f);
+    if (refl.empty()) refl.assign(4, 0);
 
     IMX_REQUIRE(imx_device_count() > 0, "imx_mesh_create: no GPU visible");
     auto m = std::make_unique<imx_mesh>();
@@ -185,16 +260,18 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         return 0;
     };
     if (up((void**)&m->d_cell_desc, desc.data(), desc.size() * 4) || up((void**)&m->d_tile_pool, pool.data(), pool.size() * 4) ||
-        up((void**)&m->d_gtab, gtab.data(), gtab.size() * 4) || up((void**)&m->d_tri_rec, recs.data(), recs.size() * 4))
+        up((void**)&m->d_gtab, gtab.data(), gtab.size() * 4) || up((void**)&m->d_tri_rec, recs.data(), recs.size() * 4) ||
+        up((void**)&m->d_refs, refl.data(), refl.size() * 4))
         return 1;
-    m->v.cell_desc = m->d_cell_desc;
+    m->v.refs = reinterpret_cast<const int4*>(m->d_refs);
+    m->v.cell_desc = reinterpret_cast<const int4*>(m->d_cell_desc);
     m->v.tile_pool = reinterpret_cast<const float4*>(m->d_tile_pool);
     m->v.gtab = reinterpret_cast<const int2*>(m->d_gtab);
     m->v.tri_rec = reinterpret_cast<const float4*>(m->d_tri_rec);
     m->v.nx = (int)nx; m->v.ny = (int)ny; m->v.ntx = ntx; m->v.nty = nty;
     m->v.x0 = xmin; m->v.y0 = ymin; m->v.cell = cell_size; m->v.inv_cell = inv_cell;
     m->v.F = F;
-    m->num_refs = (int64_t)(recs.size() / 12);
+    m->num_refs = (int64_t)(refl.size() / 2);
     m->max_refs = max_refs;
     m->n_lattice = n_lattice;
     m->n_general = n_general;
@@ -208,6 +285,7 @@ extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
     if (m->d_cell_desc) (void)hipFree(m->d_cell_desc);
     if (m->d_tile_pool) (void)hipFree(m->d_tile_pool);
     if (m->d_gtab) (void)hipFree(m->d_gtab);
+    if (m->d_refs) (void)hipFree(m->d_refs);
     delete m;
 }
 

@@ -63,65 +63,109 @@ def _tile_pyramid_slope(n, slope, hs, vs, inverted):
     return np.rint((-h if inverted else h) / vs)
 
 
-def _tile_stairs(n, step_h, step_w, hs, vs, inverted):
-    c = (n - 1) / 2.0
-    d = np.maximum(np.abs(np.arange(n) - c)[:, None], np.abs(np.arange(n) - c)[None, :])
-    k = np.floor((c - d) / (step_w / hs)).clip(0, None)
-    k = np.minimum(k, np.floor((c - 1.0 / hs) / (step_w / hs)))
-    h = k * step_h
-    return np.rint((-h if inverted else h) / vs)
+_BOX_TRIS = np.array([[0, 1, 2], [0, 2, 3], [4, 6, 5], [4, 7, 6], [0, 4, 5], [0, 5, 1], [1, 5, 6], [1, 6, 2],
+                      [2, 6, 7], [2, 7, 3], [3, 7, 4], [3, 4, 0]], dtype=np.uint32)
 
 
-def _tile_boxes(rng, n, hs, vs, height):
-    h = np.zeros((n, n))
-    for _ in range(20):
-        w = rng.integers(int(0.3 / hs), int(1.0 / hs) + 1, size=2)
-        p = rng.integers(0, n - w.max(), size=2)
-        h[p[0]:p[0] + w[0], p[1]:p[1] + w[1]] = rng.choice([-height, height, 0.5 * height])
-    return np.rint(h / vs)
+def _box(x0, y0, x1, y1, z0, z1):
+    """Axis-aligned box as 8 vertices / 12 triangles (top = vertices 4..7), like trimesh.creation.box."""
+    v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0],
+                  [x0, y0, z1], [x1, y0, z1], [x1, y1, z1], [x0, y1, z1]], dtype=np.float32)
+    return v, _BOX_TRIS
+
+
+def _tile_mesh_stairs(size, step_h, step_w, platform, inverted):
+    """MeshPyramidStairsTerrain-like (reference isaaclab/terrains/trimesh/mesh_terrains.py, pyramid_stairs_terrain):
+    every step is a square RING of four boxes, the centre a platform box -- each xy location is covered by one box."""
+    vs, ts, nv = [], [], 0
+    half = 0.5 * size
+    n_steps = max(int((half - 0.5 * platform) / step_w), 1)
+    for k in range(n_steps + 1):
+        r = half - k * step_w
+        r_in = half - (k + 1) * step_w if k < n_steps else 0.0
+        z_top = -(k * step_h) if inverted else k * step_h
+        z_bot = z_top - max(step_h, 0.05) - (n_steps * step_h if inverted else 0.0) * 0.0 - 0.5
+        if k == n_steps:  # central platform
+            v, t = _box(-r, -r, r, r, z_bot, z_top)
+            vs.append(v); ts.append(t + nv); nv += 8
+            break
+        for (a0, b0, a1, b1) in ((-r, -r, r, -r_in), (-r, r_in, r, r), (-r, -r_in, -r_in, r_in), (r_in, -r_in, r, r_in)):
+            v, t = _box(a0, b0, a1, b1, z_bot, z_top)
+            vs.append(v); ts.append(t + nv); nv += 8
+    return np.concatenate(vs), np.concatenate(ts)
+
+
+def _tile_mesh_boxes(rng, size, grid_w, h_lo, h_hi, platform):
+    """MeshRandomGridTerrain-like: a grid of boxes with random top heights around a flat platform."""
+    vs, ts, nv = [], [], 0
+    n = int(size / grid_w)
+    off = 0.5 * (size - n * grid_w)
+    half = 0.5 * size
+    for i in range(n):
+        for j in range(n):
+            x0, y0 = -half + off + i * grid_w, -half + off + j * grid_w
+            cx, cy = x0 + 0.5 * grid_w, y0 + 0.5 * grid_w
+            h = 0.0 if max(abs(cx), abs(cy)) < 0.5 * platform else float(rng.uniform(-h_hi, h_hi))
+            if abs(h) < h_lo and h != 0.0:
+                h = np.sign(h) * h_lo
+            v, t = _box(x0, y0, x0 + grid_w, y0 + grid_w, -1.0, h)
+            vs.append(v); ts.append(t + nv); nv += 8
+    # margin ring so the tile is closed
+    if off > 1e-6:
+        for (a0, b0, a1, b1) in ((-half, -half, half, -half + off), (-half, half - off, half, half),
+                                  (-half, -half + off, -half + off, half - off), (half - off, -half + off, half, half - off)):
+            v, t = _box(a0, b0, a1, b1, -1.0, 0.0)
+            vs.append(v); ts.append(t + nv); nv += 8
+    return np.concatenate(vs), np.concatenate(ts)
 
 
 def make_rough_terrain(num_rows: int = 10, num_cols: int = 20, tile: float = 8.0, horizontal_scale: float = 0.1,
                        vertical_scale: float = 0.005, border: float = 20.0, seed: int = 0,
                        slope_threshold: float | None = 0.75):
-    """Seeded rough terrain: ``num_rows x num_cols`` tiles (random-uniform, pyramid slopes, stairs, boxes) on one
-    global height field, centred at the origin, plus a flat border ring made of 8 large triangles.
+    """Seeded rough terrain with the composition of the reference's ``ROUGH_TERRAINS_CFG``
+    (isaaclab/terrains/config/rough.py:12-51): per tile, in proportion 2:2:2:2:1:1, mesh pyramid stairs, inverted mesh
+    stairs, mesh random-grid boxes (box primitives, 12 triangles each), height-field random-uniform noise, height-field
+    pyramid slope and inverted slope (``height_field_to_mesh`` with slope-threshold snapping) -- 40 % height-field tiles
+    as in SURVEY.md section 8(d) -- centred at the origin, plus a flat border ring of 8 large triangles.  Difficulty
+    grows with the row.  Synthetic input, not a restatement of the reference's generator.
 
-    Returns ``(vertices f32[V,3], triangles u32[F,3], half_extent_xy)``; proportions follow the reference's
-    ``ROUGH_TERRAINS_CFG`` (``isaaclab/terrains/config/rough.py:12-51``) loosely -- this is synthetic input.
+    Returns ``(vertices f32[V,3], triangles u32[F,3], half_extent_xy)``.
     """
     rng = np.random.default_rng(seed)
     n = int(round(tile / horizontal_scale))
-    R, C = num_rows * n + 1, num_cols * n + 1
-    hf = np.zeros((R, C))
-    kinds = ("uniform", "slope", "slope_inv", "stairs", "stairs_inv", "boxes")
+    kinds = ("stairs", "stairs_inv", "boxes", "uniform", "stairs", "stairs_inv", "boxes", "uniform", "slope", "slope_inv")
+    hx, hy = 0.5 * num_rows * tile, 0.5 * num_cols * tile
+    vs, ts, nv = [], [], 0
     for r in range(num_rows):
         for c in range(num_cols):
             kind = kinds[(r * num_cols + c) % len(kinds)]
             difficulty = (r + 0.5) / num_rows
-            if kind == "uniform":
-                t = _tile_random_uniform(rng, n + 1, 0.02, 0.10, 0.02, vertical_scale)
-            elif kind in ("slope", "slope_inv"):
-                t = _tile_pyramid_slope(n + 1, 0.4 * difficulty, horizontal_scale, vertical_scale, kind == "slope_inv")
-            elif kind in ("stairs", "stairs_inv"):
-                t = _tile_stairs(n + 1, 0.05 + 0.18 * difficulty, 0.3, horizontal_scale, vertical_scale,
-                                 kind == "stairs_inv")
+            ox, oy = -hx + (r + 0.5) * tile, -hy + (c + 0.5) * tile  # tile centre
+            if kind in ("uniform", "slope", "slope_inv"):
+                if kind == "uniform":
+                    hf = _tile_random_uniform(rng, n + 1, 0.02, 0.10, 0.02, vertical_scale)
+                else:
+                    hf = _tile_pyramid_slope(n + 1, 0.4 * difficulty, horizontal_scale, vertical_scale, kind == "slope_inv")
+                v, t = height_field_to_mesh(hf, horizontal_scale, vertical_scale, slope_threshold)
+                v = v.copy()
+                v[:, 0] += ox - 0.5 * tile
+                v[:, 1] += oy - 0.5 * tile
             else:
-                t = _tile_boxes(rng, n + 1, horizontal_scale, vertical_scale, 0.05 + 0.15 * difficulty)
-            hf[r * n:(r + 1) * n + 1, c * n:(c + 1) * n + 1] = t
-    verts, tris = height_field_to_mesh(hf, horizontal_scale, vertical_scale, slope_threshold)
-    hx, hy = 0.5 * num_rows * tile, 0.5 * num_cols * tile
-    verts[:, 0] -= hx
-    verts[:, 1] -= hy
+                if kind in ("stairs", "stairs_inv"):
+                    v, t = _tile_mesh_stairs(tile, 0.05 + 0.18 * difficulty, 0.3, 2.0, kind == "stairs_inv")
+                else:
+                    v, t = _tile_mesh_boxes(rng, tile, 0.45, 0.05, 0.05 + 0.15 * difficulty, 2.0)
+                v = v.copy()
+                v[:, 0] += ox
+                v[:, 1] += oy
+            vs.append(v.astype(np.float32)); ts.append(t.astype(np.uint32) + np.uint32(nv)); nv += len(v)
     if border > 0:
         bx, by = hx + border, hy + border
-        V0 = len(verts)
         bv = np.array([[-bx, -by, 0], [bx, -by, 0], [bx, by, 0], [-bx, by, 0],
                        [-hx, -hy, 0], [hx, -hy, 0], [hx, hy, 0], [-hx, hy, 0]], dtype=np.float32)
         quads = [(0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
         bt = []
         for a, b, c_, d in quads:
             bt += [(a, b, c_), (a, c_, d)]
-        verts = np.concatenate([verts, bv], axis=0)
-        tris = np.concatenate([tris, (np.array(bt, dtype=np.uint32) + V0)], axis=0)
-    return verts.astype(np.float32), tris.astype(np.uint32), (hx, hy)
+        vs.append(bv); ts.append(np.array(bt, dtype=np.uint32) + np.uint32(nv)); nv += 8
+    return np.concatenate(vs).astype(np.float32), np.concatenate(ts).astype(np.uint32), (hx, hy)

@@ -51,7 +51,10 @@ def test_rough_terrain_is_seeded_and_sized():
     v1, t1, ext = make_rough_terrain(2, 2, tile=4.0, border=2.0, seed=5)
     v2, t2, _ = make_rough_terrain(2, 2, tile=4.0, border=2.0, seed=5)
     assert np.array_equal(v1, v2) and np.array_equal(t1, t2)
-    assert ext == (4.0, 4.0) and t1.shape[0] == 2 * 80 * 80 + 8 and t1.max() < len(v1)
+    assert ext == (4.0, 4.0) and t1.max() < len(v1) and t1.shape[1] == 3
+    # composition of ROUGH_TERRAINS_CFG: mesh stairs / boxes (12 triangles per box) + height-field tiles
+    v3, t3, _ = make_rough_terrain(10, 20, seed=0)
+    assert 1.0e6 < len(t3) < 1.4e6  # ~1.1-1.3 M triangles
 
 
 @pytest.mark.parametrize("task", TASKS)

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_rays(MeshView M, const Env* __restrict_
             const int ix = cell_of((sx - M.x0) * M.inv_cell, nbx), iy = cell_of((sy - M.y0) * M.inv_cell, nby);
             if (ix >= 0 && iy >= 0 && ix < M.nx && iy < M.ny) {
                 const int c = imx_cell_index(ix, iy, M.ntx);
-                const int32_t d = M.cell_desc[c];
+                const int32_t d = M.cell_desc[c].x;
                 v = (float)d;
                 if (MODE == 1) {
                     const float4* p = M.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
