@@ -330,6 +330,30 @@ int imx_articulation_update(int64_t N, int64_t J, const float* root_transforms_x
 int imx_empirical_normalization(int64_t N, int64_t D, const float* x_d, int update, float eps, float* mean_d, float* var_d,
                                 float* std_d, float* count_d, float* out_d, imx_stream_t stream);
 
+/* ---- actor / critic MLP inside PPO.update (rsl_rl v2.3.1 ppo.py::update `loss.backward()` through the nn.Linear / nn.ELU
+ * stacks of actor_critic.py; 3rd party, absent: PARITY UNPINNED, checked against torch autograd).  fp32 on the f32 MFMA.
+ * The wide forward / dX GEMMs stay library calls; these are the shapes a library GEMM handles badly. */
+
+/* Bytes of scratch imx_mlp_dw / imx_mlp_head_bwd need for a layer (out_features x in_features) at M samples. */
+size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_features);
+
+/* nn.Linear backward, parameter part: dW[N][K] = dY^T X and (db_d != NULL) db[N] = column sums of dY, for
+ * dY (M,N; row pitch ldy floats) and the layer input X (M,K; pitch ldx).  Split over the M samples across all CUs,
+ * partials summed in a fixed order (deterministic). */
+int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
+               float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream);
+
+/* Output layer forward, A <= 16 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K). */
+int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                     imx_stream_t stream);
+
+/* Output layer backward in one pass over h: dW[A][K] = dY^T h, db[A] = colsum(dY), and the gradient handed to the layer
+ * below, dprev[M][K] = (dY W) * ELU'(h) with ELU' taken from the saved output h (h > 0 ? 1 : h + elu_alpha; aten
+ * elu_backward with is_result) when has_activation != 0, else dprev = dY W. */
+int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, const float* h_d, int64_t ldh, const float* W_d, float elu_alpha,
+                     int has_activation, float* dprev_d, float* dW_d, float* db_d, void* scratch_d, size_t scratch_bytes,
+                     imx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,455 @@
+// Actor / critic MLP backward + policy-head kernels of the PPO minibatch step (fp32 in, fp32 accumulate on the f32 MFMA).
+//
+// Replaces, inside rsl_rl PPO.update's `loss.backward()` (upstream rsl_rl/algorithms/ppo.py::update, autograd of the
+// nn.Linear / nn.ELU stack built by rsl_rl/modules/actor_critic.py), the three pieces a library GEMM does badly here:
+//   * imx_mlp_dw        dW = dY^T X, db = colsum(dY): a reduction over the M = 24576 samples of a minibatch into a
+//                       small (out x in) matrix -- split over M across all CUs, partials summed in a fixed order;
+//   * imx_mlp_head_fwd  the 128 -> 12 / 128 -> 1 output layer (a skinny GEMM: 4 lanes per sample, VALU);
+//   * imx_mlp_head_bwd  the same layer backward: dW, db, dX and the ELU' of the layer below in one pass over the
+//                       activations (the accumulator tile of the dX MFMA and the B operand of the dW MFMA share lanes).
+// The wide forward / dX GEMMs stay in the library (hipBLASLt, >100 TFLOP/s at these shapes).
+// v_mfma_f32_32x32x2_f32 is an exact f32 fma chain (one rounding per product): numerics = an fp32 GEMM with this
+// summation order.  PARITY UNPINNED like the rest of the rsl_rl restatement (checked against torch autograd in tests).
+#include <algorithm>
+#include <cstdlib>
+
+#include "imx_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int DW_T = 128;          // output tile: 128 out-features x 128 in-features per workgroup (4 waves, 64x64 each)
+constexpr int DW_BM = 32;          // samples per stage
+constexpr int DW_LD = DW_T + 32;   // LDS row pitch (floats): the two half-waves (sample m, m+1) land on disjoint banks
+
+struct DwArgs {
+    int64_t M;
+    int N, K;
+    const float* dY;
+    int64_t ldy;
+    const float* X;
+    int64_t ldx;
+    float* part;     // [S][N][K]
+    float* part_db;  // [S][N] or null
+    int tn, tk, S;
+    int64_t rps;     // rows (samples) per split, multiple of DW_BM
+};
+
+// row of a 32x32 MFMA accumulator register: lanes 0-31 hold rows {0-3, 8-11, 16-19, 24-27}, lanes 32-63 the others
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// one [32 x 128] stage of a row-major matrix -> 16 registers per thread (zero beyond row_end / ncols)
+template <bool VEC>
+__device__ __forceinline__ void dw_load(float (&r)[16], const float* __restrict__ src, int64_t ld, int64_t row0, int64_t row_end,
+                                        int col0, int ncols, int t) {
+    if (VEC) {
+        const int c = col0 + 4 * (t & 31);
+        const int rr = t >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + rr + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < row_end && c < ncols) v = *reinterpret_cast<const float4*>(src + row * ld + c);
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+    } else {
+        const int c = col0 + (t & 127);
+        const int rr = t >> 7;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = row0 + rr + 2 * i;
+            r[i] = (row < row_end && c < ncols) ? src[row * ld + c] : 0.0f;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void dw_store(const float (&r)[16], float* __restrict__ s, int t) {
+    if (VEC) {
+        const int c = 4 * (t & 31), rr = t >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(s + (rr + 8 * i) * DW_LD + c) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    } else {
+        const int c = t & 127, rr = t >> 7;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[(rr + 2 * i) * DW_LD + c] = r[i];
+    }
+}
+
+// Eight waves per workgroup, two per SIMD, specialised: waves 0-3 only multiply (64 MFMAs per stage from LDS, operands
+// ping-ponged so the LDS latency hides behind the previous four MFMAs), waves 4-7 only move data (global -> registers one
+// stage ahead, registers -> the other LDS buffer).  One barrier per stage; the movers' ~1000 cycles of address
+// arithmetic, predicated loads and LDS writes run on the issue slots the 4096-cycle MFMA stream leaves free, instead of
+// in front of it (a single-role kernel measured 58 % of the f32 MFMA peak in its main loop for exactly that reason).
+template <bool YVEC, bool XVEC>
+__global__ void __launch_bounds__(512, 1) k_mlp_dw(DwArgs a) {
+    __shared__ float sY[2][DW_BM * DW_LD];
+    __shared__ float sX[2][DW_BM * DW_LD];
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so give every XCD whole splits -- the
+    // tn*tk tiles of one split read the same [rps x (N + K)] slab of dY and X and share it through that XCD's L2
+    const int T = a.tn * a.tk;
+    int tile, s;
+    if ((a.S & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % T;
+        s = (j / T) * 8 + xcd;
+    } else {
+        tile = blockIdx.x % T;
+        s = blockIdx.x / T;
+    }
+    const int n0 = (tile / a.tk) * DW_T, k0 = (tile % a.tk) * DW_T;
+    const int64_t m_begin = (int64_t)s * a.rps, m_end = std::min<int64_t>(m_begin + a.rps, a.M);
+    const int nst = (int)((m_end - m_begin + DW_BM - 1) / DW_BM);
+    const bool want_db = a.part_db != nullptr && (tile % a.tk) == 0;
+
+    if (threadIdx.x >= 256) {
+        // ------------------------------------------------------------------------------------------------ movers
+        const int t = threadIdx.x - 256;
+        float ry[16], rx[16];
+        float dbv[4] = {0.f, 0.f, 0.f, 0.f};  // column sums of the dY slab (YVEC: 4 columns x rows t>>5 + 8i; else 1 column)
+        auto load = [&](int st) {
+            const int64_t row0 = m_begin + (int64_t)st * DW_BM;  // rows >= m_end load as zeros
+            dw_load<YVEC>(ry, a.dY, a.ldy, row0, m_end, n0, a.N, t);
+            dw_load<XVEC>(rx, a.X, a.ldx, row0, m_end, k0, a.K, t);
+        };
+        auto store = [&](int buf) {
+            dw_store<YVEC>(ry, sY[buf], t);
+            dw_store<XVEC>(rx, sX[buf], t);
+            if (want_db) {
+                if (YVEC) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { dbv[0] += ry[4 * i]; dbv[1] += ry[4 * i + 1]; dbv[2] += ry[4 * i + 2]; dbv[3] += ry[4 * i + 3]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dbv[0] += ry[i];
+                }
+            }
+        };
+        if (nst > 0) {
+            load(0);
+            store(0);
+            if (nst > 1) load(1);
+        }
+        __syncthreads();  // stage 0 is in LDS
+        for (int st = 0; st < nst; ++st) {
+            if (st + 1 < nst) {
+                store((st + 1) & 1);  // that buffer was last read in stage st-1: every wave is past that barrier
+                if (st + 2 < nst) load(st + 2);
+            }
+            __syncthreads();
+        }
+        if (want_db) {  // fixed-order sum of the row groups through LDS (the tile buffers are free now)
+            float* red = sY[0];
+            if (YVEC) {
+                const int c = 4 * (t & 31), rr = t >> 5;
+                *reinterpret_cast<float4*>(red + rr * DW_T + c) = make_float4(dbv[0], dbv[1], dbv[2], dbv[3]);
+            } else {
+                red[(t >> 7) * DW_T + (t & 127)] = dbv[0];
+            }
+        }
+        __syncthreads();
+        if (want_db && t < DW_T && n0 + t < a.N) {
+            const float* red = sY[0];
+            float sum = 0.0f;
+            const int groups = YVEC ? 8 : 2;
+            for (int g = 0; g < groups; ++g) sum += red[g * DW_T + t];
+            a.part_db[(size_t)s * a.N + n0 + t] = sum;
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------ multipliers
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6, r = lane & 31, half = lane >> 5;
+    const int wn = w & 1, wk = w >> 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const float* py = sY[st & 1] + half * DW_LD + wn * 64 + r;
+        const float* px = sX[st & 1] + half * DW_LD + wk * 64 + r;
+        // Operand ping-pong (P, Q): the LDS reads of step kk+1 are issued BEFORE the four MFMAs of step kk and waited
+        // for after them; the scheduling barriers keep the compiler from sinking the reads behind the MFMAs again.
+        float p0 = py[0], p1 = py[32], p2 = px[0], p3 = px[32], q0, q1, q2, q3;
+#pragma unroll
+        for (int kk = 0; kk < DW_BM / 2; kk += 2) {
+            q0 = py[(kk + 1) * 2 * DW_LD]; q1 = py[(kk + 1) * 2 * DW_LD + 32];
+            q2 = px[(kk + 1) * 2 * DW_LD]; q3 = px[(kk + 1) * 2 * DW_LD + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, p2, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, p3, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, p2, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, p3, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < DW_BM / 2) {
+                p0 = py[(kk + 2) * 2 * DW_LD]; p1 = py[(kk + 2) * 2 * DW_LD + 32];
+                p2 = px[(kk + 2) * 2 * DW_LD]; p3 = px[(kk + 2) * 2 * DW_LD + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, q2, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, q3, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, q2, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, q3, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // partial tile of this split (rows = out-features on the accumulator registers, columns = in-features on the lanes)
+    float* part = a.part + (size_t)s * a.N * a.K;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+            const int k = k0 + wk * 64 + bj * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = n0 + wn * 64 + bi * 32 + acc_row(q, half);
+                if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = acc[bi][bj][q];
+            }
+        }
+    __syncthreads();  // pairs with the movers' barrier before their bias-gradient sum
+}
+
+// out[i] = sum_s part[s][i]: 64 consecutive outputs x 16 interleaved slices of the S partials per workgroup, slices
+// combined in a fixed order (deterministic); the bias gradients ride behind the weights in the same index space
+constexpr int RED_Y = 16;
+__global__ void __launch_bounds__(64 * RED_Y) k_mlp_reduce(int64_t total, int S, const float* __restrict__ part, float* __restrict__ out,
+                                                          int N, const float* __restrict__ part_db, float* __restrict__ db) {
+    __shared__ float red[RED_Y][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    const float* src = nullptr;
+    int64_t stride = 0;
+    float* dst = nullptr;
+    if (i < total) {
+        src = part + i; stride = total; dst = out + i;
+    } else if (db && i - total < N) {
+        src = part_db + (i - total); stride = N; dst = db + (i - total);
+    }
+    float acc = 0.0f;
+    if (src)
+        for (int s = ty; s < S; s += RED_Y) acc += src[(size_t)s * stride];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && dst) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int y = 0; y < RED_Y; ++y) sum += red[y][tx];
+        *dst = sum;
+    }
+}
+
+struct DwPlan {
+    int tn, tk, S;
+    int64_t rps;
+};
+
+int g_num_cu = 0;
+
+DwPlan dw_plan(int64_t M, int N, int K) {
+    if (g_num_cu == 0) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            cu = 256;
+        g_num_cu = cu;
+    }
+    DwPlan p;
+    p.tn = (N + DW_T - 1) / DW_T;
+    p.tk = (K + DW_T - 1) / DW_T;
+    const int T = p.tn * p.tk;
+    static const int wg_per_cu = getenv("IMX_DW_WG_PER_CU") ? std::max(1, atoi(getenv("IMX_DW_WG_PER_CU"))) : 1;
+    int64_t S = std::max<int64_t>(1, (int64_t)g_num_cu * wg_per_cu / T);  // one 8-wave workgroup (80 KB of LDS) per CU
+    S = std::min<int64_t>(S, std::max<int64_t>(1, M / (2 * DW_BM)));  // at least two stages per split
+    if (S >= 8) S &= ~(int64_t)7;
+    p.rps = ((M + S - 1) / S + DW_BM - 1) / DW_BM * DW_BM;
+    p.S = (int)((M + p.rps - 1) / p.rps);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------------------- head
+constexpr int HEAD_A = 16;  // widest output layer handled (actions / value)
+
+__global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, const float* __restrict__ h, int64_t ldh,
+                                                  const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y) {
+    extern __shared__ float sW[];  // [A][K]
+    for (int i = threadIdx.x; i < A * K; i += blockDim.x) sW[i] = W[i];
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = row < M;
+    float acc[HEAD_A];
+#pragma unroll
+    for (int o = 0; o < HEAD_A; ++o) acc[o] = 0.0f;
+    const float* hr = h + (live ? row : 0) * ldh;
+    for (int k = 4 * q; k < K; k += 16) {  // the 4 lanes of a sample read one 64-byte run per trip
+        const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+#pragma unroll
+        for (int o = 0; o < HEAD_A; ++o)
+            if (o < A) {
+                const float4 wv = *reinterpret_cast<const float4*>(sW + o * K + k);
+                acc[o] = fmaf(hv.w, wv.w, fmaf(hv.z, wv.z, fmaf(hv.y, wv.y, fmaf(hv.x, wv.x, acc[o]))));
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_A; ++o)
+        if (o < A) {
+            float v = acc[o];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (q == 0 && live) y[row * A + o] = v + b[o];
+        }
+}
+
+// One wave per 32 in-features.  Per block of 32 samples: dX = dY W on the matrix core (A <= 32 reduction steps of 2), the
+// accumulator tile (sample rows on the registers, in-feature on the lane) times ELU'(h) -> d of the layer below, and the
+// same h registers as the B operand of dW += dY^T h.
+__global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const float* __restrict__ dY, const float* __restrict__ h,
+                                                    int64_t ldh, const float* __restrict__ W, float alpha, int has_act,
+                                                    float* __restrict__ dprev, float* __restrict__ part, float* __restrict__ part_db) {
+    const int lane = threadIdx.x & 63, kb = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+    const int kc = kb * 32 + r;  // this lane's in-feature
+    const int steps = (A + 1) >> 1;
+    float wreg[HEAD_A / 2];
+#pragma unroll
+    for (int s = 0; s < HEAD_A / 2; ++s) {
+        const int o = 2 * s + half;
+        wreg[s] = (s < steps && o < A) ? W[o * K + kc] : 0.0f;
+    }
+    f32x16 wacc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wacc[q] = 0.0f;
+    float dbacc = 0.0f;
+    const int64_t nblk = (M + 31) / 32;
+    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+        const int64_t m0 = rb * 32;
+        float hv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t row = m0 + acc_row(q, half);
+            hv[q] = row < M ? h[row * ldh + kc] : 0.0f;
+        }
+        f32x16 dx;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dx[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < HEAD_A / 2; ++s)
+            if (s < steps) {
+                const int o = 2 * s + half;
+                const int64_t row = m0 + r;
+                const float av = (row < M && o < A) ? dY[row * A + o] : 0.0f;
+                dx = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[s], dx, 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t row = m0 + acc_row(q, half);
+            if (row < M) {
+                const float g = has_act ? (hv[q] > 0.0f ? 1.0f : hv[q] + alpha) : 1.0f;  // ELU' from the saved output
+                dprev[row * (int64_t)K + kc] = dx[q] * g;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t row = m0 + acc_row(q, half);
+            const float av = (row < M && r < A) ? dY[row * A + r] : 0.0f;
+            wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[q], wacc, 0, 0, 0);
+            dbacc += av;
+        }
+    }
+    float* p = part + (size_t)blockIdx.x * A * K;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int o = acc_row(q, half);
+        if (o < A) p[o * K + kc] = wacc[q];
+    }
+    if (kb == 0) {
+        const float tot = dbacc + __shfl_xor(dbacc, 32);
+        if (half == 0 && r < A) part_db[(size_t)blockIdx.x * A + r] = tot;
+    }
+}
+
+int head_grid(int64_t M) { return (int)std::min<int64_t>((M + 31) / 32, 256); }
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_features) {
+    if (M <= 0 || out_features <= 0 || in_features <= 0) return 0;
+    size_t dw = 0;
+    {
+        const DwPlan p = dw_plan(M, out_features, in_features);
+        dw = ((size_t)p.S * out_features * in_features + (size_t)p.S * out_features) * sizeof(float);
+    }
+    const size_t head = out_features <= HEAD_A
+                            ? ((size_t)head_grid(M) * out_features * in_features + (size_t)head_grid(M) * out_features) * sizeof(float)
+                            : 0;
+    return std::max(dw, head) + 256;
+}
+
+extern "C" int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
+                          float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && N > 0 && K > 0 && dY_d && X_d && dW_d && scratch_d, "imx_mlp_dw: bad arguments");
+    IMX_REQUIRE(ldy >= N && ldx >= K, "imx_mlp_dw: row pitch smaller than the row (ldy=%lld N=%d, ldx=%lld K=%d)", (long long)ldy, N,
+                (long long)ldx, K);
+    const DwPlan p = dw_plan(M, N, K);
+    const size_t need = ((size_t)p.S * N * K + (size_t)p.S * N) * sizeof(float);
+    IMX_REQUIRE(scratch_bytes >= need, "imx_mlp_dw: scratch too small (%zu < %zu bytes; see imx_mlp_scratch_bytes)", scratch_bytes, need);
+    DwArgs a;
+    a.M = M; a.N = N; a.K = K;
+    a.dY = dY_d; a.ldy = ldy; a.X = X_d; a.ldx = ldx;
+    a.part = (float*)scratch_d;
+    a.part_db = db_d ? a.part + (size_t)p.S * N * K : nullptr;
+    a.tn = p.tn; a.tk = p.tk; a.S = p.S; a.rps = p.rps;
+    const bool yvec = (N % 4 == 0) && (ldy % 4 == 0) && aligned16(dY_d);
+    const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X_d);
+    const dim3 grid((unsigned)(p.tn * p.tk * p.S)), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (yvec && xvec) hipLaunchKernelGGL((k_mlp_dw<true, true>), grid, block, 0, st, a);
+    else if (yvec) hipLaunchKernelGGL((k_mlp_dw<true, false>), grid, block, 0, st, a);
+    else if (xvec) hipLaunchKernelGGL((k_mlp_dw<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_dw<false, false>), grid, block, 0, st, a);
+    IMX_HIP(hipGetLastError());
+    const int64_t total = (int64_t)N * K, threads = total + (db_d ? N : 0);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((threads + 63) / 64)), dim3(64, RED_Y), 0, st, total, p.S, a.part, dW_d, N, a.part_db, db_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                                imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && h_d && W_d && b_d && y_d, "imx_mlp_head_fwd: bad arguments");
+    IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_fwd: %d outputs (1..%d supported; wider layers are library GEMMs)", A, HEAD_A);
+    IMX_REQUIRE(K >= 16 && K % 16 == 0 && K <= 2048 && ldh >= K && ldh % 4 == 0 && aligned16(h_d),
+                "imx_mlp_head_fwd: in-features %d (pitch %lld) must be a multiple of 16, 16-byte aligned rows", K, (long long)ldh);
+    hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M, K, A,
+                       h_d, ldh, W_d, b_d, y_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, const float* h_d, int64_t ldh, const float* W_d, float elu_alpha,
+                                int has_activation, float* dprev_d, float* dW_d, float* db_d, void* scratch_d, size_t scratch_bytes,
+                                imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && dY_d && h_d && W_d && dprev_d && dW_d && db_d && scratch_d, "imx_mlp_head_bwd: bad arguments");
+    IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_bwd: %d outputs (1..%d supported)", A, HEAD_A);
+    IMX_REQUIRE(K >= 32 && K % 32 == 0 && K <= 256 && ldh >= K, "imx_mlp_head_bwd: in-features %d must be a multiple of 32, at most 256", K);
+    const int G = head_grid(M);
+    const size_t need = ((size_t)G * A * K + (size_t)G * A) * sizeof(float);
+    IMX_REQUIRE(scratch_bytes >= need, "imx_mlp_head_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need);
+    float* part = (float*)scratch_d;
+    float* part_db = part + (size_t)G * A * K;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)G), dim3((unsigned)(K / 32 * 64)), 0, st, M, K, A, dY_d, h_d, ldh, W_d, elu_alpha,
+                       has_activation, dprev_d, part, part_db);
+    IMX_HIP(hipGetLastError());
+    const int64_t total = (int64_t)A * K, threads = total + A;
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((threads + 63) / 64)), dim3(64, RED_Y), 0, st, total, G, part, dW_d, A, part_db, db_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

@@ -118,12 +118,32 @@ def _mlp_layers(seq: nn.Sequential):
     return out
 
 
+HEAD_MAX_OUT = 16  # imx_mlp_head_*: output layers up to 16 wide (action means, value)
+
+
+def _is_head(lin: nn.Linear, x: torch.Tensor) -> bool:
+    return (lin.out_features <= HEAD_MAX_OUT and lin.in_features % 32 == 0 and lin.in_features <= 256
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0)
+
+
+def mlp_scratch(layers, M: int, device) -> torch.Tensor:
+    """Scratch for ``mlp_backward`` (one per network: actor and critic run on two streams at once)."""
+    n = max(int(lib().imx_mlp_scratch_bytes(M, lin.out_features, lin.in_features)) for lin, _ in layers)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 def mlp_forward(layers, x):
-    """Returns (output, saved layer inputs).  ELU layers run in place on the GEMM output."""
+    """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
+    the narrow output layer: ``imx_mlp_head_fwd``."""
     saved = [x]
     h = x
     for lin, act in layers:
-        z = torch.addmm(lin.bias, h, lin.weight.t())  # GEMM + bias epilogue (hipBLASLt)
+        if act is None and _is_head(lin, h):
+            z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
+            check(lib().imx_mlp_head_fwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
+                                         lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), _lib.current_stream(h.device)))
+        else:
+            z = torch.addmm(lin.bias, h, lin.weight.t())  # GEMM + bias epilogue (hipBLASLt)
         if act is None:
             h = z
         elif isinstance(act, nn.ELU):
@@ -135,19 +155,38 @@ def mlp_forward(layers, x):
     return h, saved
 
 
-def mlp_backward(layers, saved, dout):
-    """Writes dW/db of every layer straight into ``param.grad`` (views of the flat bucket)."""
+def mlp_backward(layers, saved, dout, scratch=None):
+    """Writes dW/db of every layer straight into ``param.grad`` (views of the flat bucket).  dW / db: ``imx_mlp_dw``
+    (split over the samples on the f32 MFMA); output layer: ``imx_mlp_head_bwd`` (dW, db, dX and the ELU' of the layer
+    below in one pass); the wide dX GEMMs stay in the library."""
+    L = lib()
     d = dout
+    M = d.shape[0]
+    if scratch is None:
+        scratch = mlp_scratch(layers, M, d.device)
+    stream = _lib.current_stream(d.device)
     for i in range(len(layers) - 1, -1, -1):
         lin, _ = layers[i]
         x = saved[i] if not isinstance(saved[i], tuple) else saved[i][1]
-        torch.mm(d.t(), x, out=lin.weight.grad)
-        torch.sum(d, dim=0, out=lin.bias.grad)
+        prev_act = layers[i - 1][1] if i > 0 else None
+        if not d.is_contiguous():
+            d = d.contiguous()
+        if i > 0 and _is_head(lin, x) and (prev_act is None or isinstance(prev_act, nn.ELU)):
+            dprev = torch.empty(M, lin.in_features, device=d.device, dtype=d.dtype)
+            check(L.imx_mlp_head_bwd(M, lin.in_features, lin.out_features, d.data_ptr(), x.data_ptr(), x.stride(0),
+                                     lin.weight.data_ptr(), float(prev_act.alpha) if prev_act is not None else 0.0,
+                                     int(prev_act is not None), dprev.data_ptr(), lin.weight.grad.data_ptr(),
+                                     lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+            d = dprev
+            continue
+        check(L.imx_mlp_dw(M, lin.out_features, lin.in_features, d.data_ptr(), d.stride(0), x.data_ptr(), x.stride(0),
+                           lin.weight.grad.data_ptr(), lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
         if i > 0:
             dx = torch.mm(d, lin.weight)
-            prev_act = layers[i - 1][1]
             if isinstance(prev_act, nn.ELU):  # ELU'(z) from the saved output: y > 0 ? 1 : y + alpha
                 d = torch.ops.aten.elu_backward(dx, prev_act.alpha, 1.0, 1.0, True, saved[i])
+            elif prev_act is None:
+                d = dx
             else:
                 z, _h = saved[i]
                 with torch.enable_grad():
@@ -245,7 +284,8 @@ class PPO:
         if ws is None:
             dev = self.device
             ws = dict(dmu=torch.empty(M, A, device=dev), dsigma=torch.empty(M, A, device=dev), dvalue=torch.empty(M, 1, device=dev),
-                      scratch=torch.empty(int(lib().imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device=dev))
+                      scratch=torch.empty(int(lib().imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device=dev),
+                      mlp_a=mlp_scratch(self._actor_layers, M, dev), mlp_c=mlp_scratch(self._critic_layers, M, dev))
             self._ws[(M, A)] = ws
         return ws
 
@@ -291,12 +331,12 @@ class PPO:
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
-            mlp_backward(self._actor_layers, saved_a, ws["dmu"])
+                mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             main.wait_stream(side)
         else:
-            mlp_backward(self._actor_layers, saved_a, ws["dmu"])
-            mlp_backward(self._critic_layers, saved_c, ws["dvalue"])
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
+            mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
         self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
         return self._out8
 

@@ -50,6 +50,15 @@ def test_raycast_matches_brute_force_oracles():
         assert np.array_equal(dist[~miss], t32[~miss]), f"cell={cell}"
         assert np.abs(hits[~miss] - h64[~miss]).max() <= 1e-5
         assert mesh.num_triangles == len(t)
+    # upward rays (no top-sorted early exit on this side): from below the terrain into box bottoms / height-field quads
+    up_s = starts[:4000].copy()
+    up_s[:, 2] = -5.0
+    up_d = np.tile(np.array([0, 0, 1], np.float32), (4000, 1))
+    _, dist, _, _ = mesh.raycast(torch.from_numpy(up_s).cuda(), torch.from_numpy(up_d).cuda(), 1e6, True, True)
+    _, t32, _ = raycast_woop_f32(v, t, up_s, up_d)
+    dist = dist.cpu().numpy()
+    assert np.array_equal(np.isfinite(dist), np.isfinite(t32)) and np.isfinite(t32).sum() > 3000
+    assert np.array_equal(dist[np.isfinite(t32)], t32[np.isfinite(t32)])
     # general (slanted) rays through the DDA path
     R2 = 4000
     s2 = np.stack([rng.uniform(-5, 5, R2), rng.uniform(-7, 7, R2), rng.uniform(0.5, 3, R2)], 1).astype(np.float32)
@@ -163,6 +172,71 @@ def test_explicit_backward_matches_autograd(libimx):
     assert float(err) < 1e-5, f"flat gradient bucket: max err / max |g| = {float(err):.2e}"  # fp32 GEMM summation order
     assert_close(got[:n], ref, 1e-5, "flat gradient bucket")
     assert abs(float(got[n]) - float(kl)) < 1e-6  # KL rides in the trailing slot
+
+
+@pytest.mark.parametrize("M,N,K", [(24576, 512, 235), (1000, 256, 512), (4099, 128, 256), (333, 130, 37), (5, 64, 48)])
+def test_mlp_dw_matches_fp64(libimx, M, N, K):
+    """imx_mlp_dw (split over samples on the f32 MFMA): dW = dY^T X, db = colsum(dY) against an fp64 product."""
+    from isaaclab_amd import _lib
+
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, N, generator=g).cuda()
+    X = torch.randn(M, K, generator=g).cuda()
+    dW = torch.full((N, K), float("nan"), device="cuda")
+    db = torch.full((N,), float("nan"), device="cuda")
+    nbytes = int(libimx.imx_mlp_scratch_bytes(M, N, K))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), scratch.data_ptr(), nbytes, st))
+    ref = dY.double().t() @ X.double()
+    scale = float((dY.double().abs().t() @ X.double().abs()).max())  # sum |a b|: the fp32 error scale of a dot product
+    assert float((dW.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((db.double() - dY.double().sum(0)).abs().max()) <= 2e-6 * float(dY.abs().sum(0).max())
+    # same call again: bit-identical (fixed summation order), also with a strided (non-16-byte-pitch) input view
+    dW2 = torch.empty_like(dW)
+    _lib.check(libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW2.data_ptr(), None, scratch.data_ptr(), nbytes, st))
+    assert torch.equal(dW, dW2)
+    Xp = torch.zeros(M, K + 3, device="cuda")
+    Xp[:, :K] = X
+    _lib.check(libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, Xp.data_ptr(), K + 3, dW2.data_ptr(), None, scratch.data_ptr(), nbytes, st))
+    assert torch.equal(dW, dW2)
+    assert libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), None, scratch.data_ptr(), 16, st) != 0
+
+
+@pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5)])
+def test_mlp_head_matches_autograd(libimx, M, K, A):
+    """imx_mlp_head_fwd / imx_mlp_head_bwd against torch (fp64) for the layer  y = ELU(z) W^T + b."""
+    from isaaclab_amd import _lib
+
+    g = torch.Generator().manual_seed(K + A)
+    z = torch.randn(M, K, generator=g).cuda()
+    W = (0.2 * torch.randn(A, K, generator=g)).cuda()
+    b = torch.randn(A, generator=g).cuda()
+    dY = torch.randn(M, A, generator=g).cuda()
+    alpha = 1.0
+    zd = z.double().requires_grad_(True)
+    Wd, bd = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    hd = torch.nn.functional.elu(zd, alpha)
+    yd = hd @ Wd.t() + bd
+    yd.backward(dY.double())
+    h = hd.detach().float()
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(M, A, device="cuda")
+    _lib.check(libimx.imx_mlp_head_fwd(M, K, A, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st))
+    assert float((y.double() - yd.detach()).abs().max()) <= 1e-5
+    nbytes = int(libimx.imx_mlp_scratch_bytes(M, A, K))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dprev, dW, db = torch.empty(M, K, device="cuda"), torch.empty(A, K, device="cuda"), torch.empty(A, device="cuda")
+    _lib.check(libimx.imx_mlp_head_bwd(M, K, A, dY.data_ptr(), h.data_ptr(), K, W.data_ptr(), alpha, 1, dprev.data_ptr(), dW.data_ptr(),
+                                       db.data_ptr(), scratch.data_ptr(), nbytes, st))
+    assert float((dprev.double() - zd.grad).abs().max()) <= 1e-5
+    assert float((dW.double() - Wd.grad).abs().max()) <= 2e-6 * float((dY.double().abs().t() @ hd.detach().abs()).max())
+    assert float((db.double() - bd.grad).abs().max()) <= 2e-6 * float(dY.abs().sum(0).max())
+    # no activation below: dprev = dY W
+    _lib.check(libimx.imx_mlp_head_bwd(M, K, A, dY.data_ptr(), h.data_ptr(), K, W.data_ptr(), 0.0, 0, dprev.data_ptr(), dW.data_ptr(),
+                                       db.data_ptr(), scratch.data_ptr(), nbytes, st))
+    assert float((dprev.double() - dY.double() @ W.double()).abs().max()) <= 1e-5
+    assert libimx.imx_mlp_head_fwd(M, K, 17, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st) != 0
 
 
 def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx):
