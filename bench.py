@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 TASK = "Isaac-Velocity-Rough-Anymal-C-v0"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, exact f32 in / f32 accumulate (155 TF measured)
 
 
 def obs_kernel_bytes_per_env(plan) -> float:
@@ -169,6 +170,45 @@ def cpu_baseline(task, num_envs, T, budget_s=12.0):
                       f"{ncpu} host cores visible; probe {probe_s}"}
 
 
+def time_mlp_dw(alg, M: int, device, launches: int = 30) -> dict:
+    """imx_mlp_dw (k_mlp_dw + k_mlp_reduce) on the hidden-layer shapes of the actor at the minibatch size, isolated
+    launches on the current stream, HIP events around each shape's batch.  flops = 2*M*out*in per launch."""
+    from isaaclab_amd._lib import check, current_stream, lib
+    from isaaclab_amd.rsl_rl.ppo import HEAD_MAX_OUT
+
+    L = lib()
+    st = current_stream(device)
+    flops = 0.0
+    secs = 0.0
+    shapes = []
+    for lin, _ in alg._actor_layers:
+        N, K = lin.out_features, lin.in_features
+        if N <= HEAD_MAX_OUT:
+            continue
+        dY = torch.randn(M, N, device=device)
+        X = torch.randn(M, K, device=device)
+        dW, db = torch.empty(N, K, device=device), torch.empty(N, device=device)
+        nb = int(L.imx_mlp_scratch_bytes(M, N, K))
+        scr = torch.empty(nb, dtype=torch.uint8, device=device)
+        args = (M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st)
+        for _ in range(3):
+            check(L.imx_mlp_dw(*args))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(launches):
+            check(L.imx_mlp_dw(*args))
+        b.record()
+        torch.cuda.synchronize(device)
+        t = a.elapsed_time(b) * 1e-3 / launches
+        shapes.append({"out": N, "in": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12})
+        flops += 2.0 * M * N * K
+        secs += t
+    n = max(len(shapes), 1)
+    return {"bound": "mfma", "kernel": "k_mlp_dw + k_mlp_reduce (imx_mlp_dw: dW = dY^T X, db; hidden layers of the actor, isolated launches)",
+            "achieved": flops / secs / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "flops_per_launch": flops / n, "avg_launch_us": secs / n * 1e6, "samples": M, "per_layer": shapes}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +330,13 @@ def main():
                 del env_big
             except Exception as exc:  # secondary measurement only
                 out["roofline_large_n"] = {"error": str(exc)}
+        try:  # the largest hand-written kernel of the update, against the f32 MFMA peak
+            mb = args.num_envs * T // int(runner.alg.num_mini_batches)
+            out["roofline_mfma"] = time_mlp_dw(runner.alg, mb, device)
+            if os.path.exists(tf):
+                out["roofline_mfma"]["traffic"] = json.load(open(tf)).get("k_mlp_dw_bytes_per_launch")
+        except Exception as exc:  # secondary measurement only
+            out["roofline_mfma"] = {"error": str(exc)}
         out["ppo"] = {k: round(v, 6) for k, v in stats.items()}
         out["ppo"]["learning_rate"] = runner.alg.learning_rate
         if world == 1 and not args.no_cpu_baseline:

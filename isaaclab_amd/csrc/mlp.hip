@@ -7,7 +7,9 @@
 //   * imx_mlp_head_fwd  the 128 -> 12 / 128 -> 1 output layer (a skinny GEMM: 4 lanes per sample, VALU);
 //   * imx_mlp_head_bwd  the same layer backward: dW, db, dX and the ELU' of the layer below in one pass over the
 //                       activations (the accumulator tile of the dX MFMA and the B operand of the dW MFMA share lanes).
-// The wide forward / dX GEMMs stay in the library (hipBLASLt, >100 TFLOP/s at these shapes).
+// The wide forward / dX GEMMs stay in the library (hipBLASLt, 100-130 TFLOP/s at these shapes; a hand-written fused
+// Linear+ELU forward on the same skeleton measured 52-78 TFLOP/s -- slower than library GEMM + separate ELU pass -- and
+// was dropped).
 // v_mfma_f32_32x32x2_f32 is an exact f32 fma chain (one rounding per product): numerics = an fp32 GEMM with this
 // summation order.  PARITY UNPINNED like the rest of the rsl_rl restatement (checked against torch autograd in tests).
 #include <algorithm>
