@@ -373,8 +373,8 @@ extern "C" int imx_adam_update(int64_t n, float* p, const float* g, float* m, fl
 
 // ------------------------------------------------------------------------------------------------- minibatch gather
 // RolloutStorage.mini_batch_generator: obs[idx], actions[idx], values[idx], ... -- one launch for all (<= 12) arrays.
-// The arrays are treated as one virtual row of sum(width) floats per sample; lane = (sample, column) so the stores
-// are contiguous per array and the loads are contiguous inside a gathered row.
+// One wave per sample row (two rows in flight): idx[r] is read once per row, the array loop is uniform (no per-element
+// division, no per-lane pointer table look-up), lanes run along the row so loads and stores are contiguous.
 struct GatherArgs {
     const float* src[12];
     float* dst[12];
@@ -383,16 +383,23 @@ struct GatherArgs {
     int n;
 };
 __global__ void __launch_bounds__(256) k_gather_rows(int64_t M, const int64_t* __restrict__ idx, GatherArgs a) {
-    const int total = a.offset[a.n];
-    const int64_t nel = M * total;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nel; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / total;
-        const int c = (int)(i - r * total);
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < 12; ++q) k += (q < a.n && c >= a.offset[q]) ? 1 : 0;
-        const int cc = c - a.offset[k];
-        a.dst[k][r * a.width[k] + cc] = a.src[k][idx[r] * a.width[k] + cc];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = 2 * wave; r0 < M; r0 += 2 * nw) {
+        const int64_t r1 = r0 + 1;
+        const bool two = r1 < M;
+        const int64_t s0 = idx[r0], s1 = two ? idx[r1] : 0;
+        for (int k = 0; k < a.n; ++k) {
+            const int w = a.width[k];
+            const float* __restrict__ src = a.src[k];
+            float* __restrict__ dst = a.dst[k];
+            for (int c = lane; c < w; c += 64) {
+                const float v0 = src[s0 * w + c];
+                const float v1 = two ? src[s1 * w + c] : 0.0f;
+                dst[r0 * w + c] = v0;
+                if (two) dst[r1 * w + c] = v1;
+            }
+        }
     }
 }
 
@@ -409,8 +416,7 @@ extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const voi
         IMX_REQUIRE(k >= n || (a.src[k] && a.dst[k] && a.width[k] > 0), "imx_gather_rows: array %d is null or empty", k);
         a.offset[k + 1] = a.offset[k] + a.width[k];
     }
-    const int64_t nel = M * a.offset[n];
-    const unsigned grid = (unsigned)std::min<int64_t>((nel + 255) / 256, 8192);
+    const unsigned grid = (unsigned)std::min<int64_t>((M + 7) / 8, 4096);  // 4 waves per block, 2 rows per wave and trip
     hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, idx_d, a);
     IMX_HIP(hipGetLastError());
     return 0;

@@ -132,14 +132,17 @@ def mlp_scratch(layers, M: int, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def mlp_forward(layers, x):
+def mlp_forward(layers, x, out=None):
     """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
-    the narrow output layer: ``imx_mlp_head_fwd``."""
+    the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given)."""
     saved = [x]
     h = x
-    for lin, act in layers:
+    for li, (lin, act) in enumerate(layers):
         if act is None and _is_head(lin, h):
-            z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
+            if out is not None and li == len(layers) - 1:
+                z = out
+            else:
+                z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
             check(lib().imx_mlp_head_fwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
                                          lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), _lib.current_stream(h.device)))
         else:
@@ -152,6 +155,9 @@ def mlp_forward(layers, x):
         else:
             h = act(z)
             saved.append((z, h))
+    if out is not None and h is not out:
+        out.copy_(h)
+        h = out
     return h, saved
 
 
@@ -279,6 +285,11 @@ class PPO:
             self._side = torch.cuda.Stream(self.device)
         return self._side
 
+    def _aux_stream(self):
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream(self.device)
+        return self._aux
+
     def _workspace(self, M: int, A: int):
         ws = self._ws.get((M, A))
         if ws is None:
@@ -314,27 +325,40 @@ class PPO:
             sigma, sstride = pol.std, 0
         else:
             sigma, sstride = torch.exp(pol.log_std).expand_as(mu).contiguous(), A
-        check(L.imx_ppo_loss_fwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
-                                 old_mu.data_ptr(), old_sigma.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
-                                 value.data_ptr(), target_values.data_ptr(), float(self.clip_param),
-                                 int(self.use_clipped_value_loss), float(self.value_loss_coef), float(self.entropy_coef),
-                                 self._out8.data_ptr(), self._stats.data_ptr(), ws["scratch"].data_ptr(), stream))
+        # the gradients need only the per-sample terms: loss_bwd first, then the backward GEMMs; the loss values / KL
+        # (logging, adaptive LR) and the sigma-gradient reduction run beside them on a third stream
         check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
                                  advantages.data_ptr(), returns.data_ptr(), value.data_ptr(), target_values.data_ptr(),
                                  float(self.clip_param), int(self.use_clipped_value_loss), float(self.value_loss_coef),
                                  float(self.entropy_coef), 1.0, ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(),
                                  ws["dvalue"].data_ptr(), stream))
-        if pol.noise_std_type == "scalar":
-            torch.sum(ws["dsigma"], dim=0, out=pol.std.grad)
-        else:
-            torch.sum(ws["dsigma"] * sigma, dim=0, out=pol.log_std.grad)
+
+        def loss_values(st):
+            check(L.imx_ppo_loss_fwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
+                                     old_mu.data_ptr(), old_sigma.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
+                                     value.data_ptr(), target_values.data_ptr(), float(self.clip_param),
+                                     int(self.use_clipped_value_loss), float(self.value_loss_coef), float(self.entropy_coef),
+                                     self._out8.data_ptr(), self._stats.data_ptr(), ws["scratch"].data_ptr(), st))
+            if pol.noise_std_type == "scalar":
+                torch.sum(ws["dsigma"], dim=0, out=pol.std.grad)
+            else:
+                torch.sum(ws["dsigma"] * sigma, dim=0, out=pol.log_std.grad)
+
         if side is not None:
+            aux = self._aux_stream()
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                loss_values(aux.cuda_stream)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
             mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             main.wait_stream(side)
+            main.wait_stream(aux)
+            mu.record_stream(aux)
+            value.record_stream(aux)
         else:
+            loss_values(stream)
             mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
         self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
