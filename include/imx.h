@@ -354,6 +354,36 @@ int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, const float* h_
                      int has_activation, float* dprev_d, float* dW_d, float* db_d, void* scratch_d, size_t scratch_bytes,
                      imx_stream_t stream);
 
+/* ---- reset / interval events and terrain curriculum, masked: only rows with mask != 0 are rewritten
+ * (mask NULL = every env).  The reference runs these on a compacted env_ids list (EventManager.apply,
+ * managers/event_manager.py:150-273); draws are sample_uniform (utils/math.py:1313) = u*(hi-lo)+lo with u from the
+ * counter-based generator (seed, *step_counter_d, env, column) or from uniforms_d in parity runs. */
+
+/* reset_root_state_uniform (envs/mdp/events.py:823-868) and reset_joints_by_scale / _by_offset (:987-1049).
+ * ranges28 (HOST) = pose {x,y,z,roll,pitch,yaw} (lo,hi) x6, velocity (lo,hi) x6, joint position lo,hi, joint velocity lo,hi.
+ * joint_mode 0 = by scale, 1 = by offset, < 0 = joints untouched.  default_root_state (N,13: pos, quat wxyz, lin, ang),
+ * soft_joint_pos_limits (N,J,2), soft_joint_vel_limits (N,J).  uniforms_d: optional (N, 12 + 2J) = [pose 6 | velocity 6 |
+ * joint pos J | joint vel J].  Outputs = what write_root_pose_to_sim (N,7), write_root_velocity_to_sim (N,6) and
+ * write_joint_state_to_sim (N,J)x2 receive. */
+int imx_reset_events(int64_t N, int64_t J, const uint8_t* reset_mask_d, const float* ranges28, int joint_mode,
+                     const float* default_root_state_d, const float* env_origins_d, const float* default_joint_pos_d,
+                     const float* default_joint_vel_d, const float* soft_joint_pos_limits_d, const float* soft_joint_vel_limits_d,
+                     const float* uniforms_d, uint64_t seed, const int32_t* step_counter_d, float* root_pose_d, float* root_vel_d,
+                     float* joint_pos_d, float* joint_vel_d, imx_stream_t stream);
+
+/* push_by_setting_velocity (events.py:795-820): root_vel_w (N,6) += sample; ranges12 (HOST) = (lo,hi) x6; uniforms_d (N,6). */
+int imx_push_velocity(int64_t N, const uint8_t* mask_d, const float* ranges12, const float* uniforms_d, uint64_t seed,
+                      const int32_t* step_counter_d, float* root_vel_w_d, imx_stream_t stream);
+
+/* terrain_levels_vel (isaaclab_tasks/.../velocity/mdp/curriculums.py:26-55) + TerrainImporter.update_env_origins
+ * (terrains/terrain_importer.py:307-326): move up when the robot walked more than half a tile, down when less than half
+ * the commanded distance; levels past the last are replaced by rand_levels_d[e] (randint_like; NULL -> in-kernel draw);
+ * env_origins <- terrain_origins[level, type] (num_levels, num_types, 3); mean_level_d (optional) <- mean level. */
+int imx_terrain_levels(int64_t N, int64_t num_levels, int64_t num_types, const uint8_t* mask_d, const float* root_pos_w_d,
+                       const float* command_d, const float* terrain_origins_d, const int64_t* terrain_types_d, float terrain_size_x,
+                       float max_episode_length_s, const int64_t* rand_levels_d, uint64_t seed, const int32_t* step_counter_d,
+                       int64_t* terrain_levels_d, float* env_origins_d, float* mean_level_d, imx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

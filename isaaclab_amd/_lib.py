@@ -78,6 +78,11 @@ _SIGNATURES = {
                                      c_uint64, c_void_p] + [c_void_p] * 8 + [c_void_p]),
     "imx_articulation_update": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float] + [c_void_p] * 6 + [c_void_p]),
     "imx_empirical_normalization": (c_int, [c_int64, c_int64, c_void_p, c_int, c_float] + [c_void_p] * 5 + [c_void_p]),
+    "imx_reset_events": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_uint64, c_void_p] + [c_void_p] * 4
+                         + [c_void_p]),
+    "imx_push_velocity": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "imx_terrain_levels": (c_int, [c_int64, c_int64, c_int64] + [c_void_p] * 5 + [c_float, c_float, c_void_p, c_uint64, c_void_p]
+                           + [c_void_p] * 3 + [c_void_p]),
     "imx_mlp_scratch_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "imx_mlp_dw": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -361,7 +361,8 @@ class ManagerBasedRLEnv:
     def __init__(self, cfg: Any, render_mode: str | None = None, *, state_feed: StateFeed | None = None,
                  robot: RobotSpec | str | None = None, terrain=None, num_envs: int | None = None,
                  device: str | torch.device | None = None, seed: int | None = None, noise_seed: int = 0,
-                 terrain_cell: float = 0.0, use_command_term: bool = False, use_contact_sensor: bool = False, **kwargs):
+                 terrain_cell: float = 0.0, use_command_term: bool = False, use_contact_sensor: bool = False,
+                 events_cfg: dict | None = None, **kwargs):
         if isinstance(cfg, str):
             cfg = load_task_cfg(cfg)
         self.cfg = cfg
@@ -482,6 +483,24 @@ class ManagerBasedRLEnv:
             self.contact_sensor = ContactSensorState(N, plan.num_bodies, int(cs.get("history_length", 0)),
                                                      bool(cs.get("track_air_time", False)), float(cs.get("update_period", 0.0)),
                                                      float(cs.get("force_threshold", 1.0)), self.device)
+        # -- optional reset events run by the env on the step kernel's reset mask: what the reference's
+        # EventManager.apply("reset") hands to write_root_pose_to_sim / write_root_velocity_to_sim / write_joint_state_to_sim
+        # lands in ``sim_writes`` (the simulator itself is out of scope; the feed keeps playing its snapshots)
+        self.reset_events = None
+        if events_cfg:
+            from .events import ResetEvents
+
+            J = plan.num_joints
+            self.reset_events = ResetEvents.from_cfg(events_cfg, N, J, self.device, seed=noise_seed)
+            init = ((env_dict.get("scene") or {}).get("robot") or {}).get("init_state") or {}
+            drs = torch.zeros(N, 13, device=self.device)
+            drs[:, 0:3] = torch.tensor(init.get("pos", (0.0, 0.0, 0.6)), device=self.device)
+            drs[:, 3:7] = torch.tensor(init.get("rot", (1.0, 0.0, 0.0, 0.0)), device=self.device)
+            drs[:, 7:10] = torch.tensor(init.get("lin_vel", (0.0, 0.0, 0.0)), device=self.device)
+            drs[:, 10:13] = torch.tensor(init.get("ang_vel", (0.0, 0.0, 0.0)), device=self.device)
+            self.default_root_state = drs
+            self.sim_writes = {"root_pose": torch.zeros(N, 7, device=self.device), "root_vel": torch.zeros(N, 6, device=self.device),
+                               "joint_pos": torch.zeros(N, J, device=self.device), "joint_vel": torch.zeros(N, J, device=self.device)}
         self.scene = _Scene(self)
         self._ext_funcs = {
             "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None and t.weight != 0.0],
@@ -641,6 +660,11 @@ class ManagerBasedRLEnv:
         check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
                                                  ctypes.byref(self._bufs), _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
+        if self.reset_events is not None:  # EventManager.apply(mode="reset", env_ids=reset_env_ids) as one masked launch
+            f, w = self.feed, self.sim_writes
+            self.reset_events.reset(self.reset_buf, self.default_root_state, f["env_origins"], w["root_pose"], w["root_vel"],
+                                    f["default_joint_pos"], f["default_joint_vel"], f["soft_joint_pos_limits"],
+                                    f["soft_joint_vel_limits"], w["joint_pos"], w["joint_vel"])
         # -- commands: CommandTerm.reset for the reset envs + CommandManager.compute(dt) (one kernel), or from the feed
         if self.command_term is not None:
             f = self.feed

@@ -209,6 +209,40 @@ def test_env_owned_command_term_and_contact_sensor():
     env.close()
 
 
+def test_env_owned_reset_events():
+    """SURVEY 8f row 2 wired into the env: the step kernel's reset mask drives imx_reset_events; what the reference's
+    EventManager would write to the simulator lands in env.sim_writes for exactly the envs that reset."""
+    from isaaclab_amd.env import ManagerBasedRLEnv
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    events = {"reset_base": {"func": "isaaclab.envs.mdp.events:reset_root_state_uniform", "mode": "reset",
+                             "params": {"pose_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-3.14, 3.14)}, "velocity_range": {}}},
+              "reset_robot_joints": {"func": "isaaclab.envs.mdp.events:reset_joints_by_scale", "mode": "reset",
+                                     "params": {"position_range": (0.5, 1.5), "velocity_range": (0.0, 0.0)}}}
+    env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), events_cfg=events)
+    env.reset()
+    a = torch.zeros(64, 12, device="cuda:0")
+    ever = torch.zeros(64, dtype=torch.bool, device="cuda:0")
+    for _ in range(4):
+        before = {k: v.clone() for k, v in env.sim_writes.items()}
+        _, _, term, tout, _ = env.step(a)
+        done = term | tout
+        ever |= done
+        for k, v in env.sim_writes.items():
+            assert torch.equal(v[~done], before[k][~done])  # untouched rows
+        d = env.sim_writes["root_pose"][done, :3] - env.feed["env_origins"][done] - env.default_root_state[done, :3]
+        if done.any():
+            assert float(d[:, :2].abs().max()) <= 0.5 + 1e-6 and float(d[:, 2].abs().max()) <= 1e-6
+            jp, dj = env.sim_writes["joint_pos"][done], env.feed["default_joint_pos"][done]
+            lim = env.feed["soft_joint_pos_limits"][done]
+            expect_lo = torch.minimum(dj * 0.5, dj * 1.5).clamp(lim[..., 0], lim[..., 1])
+            expect_hi = torch.maximum(dj * 0.5, dj * 1.5).clamp(lim[..., 0], lim[..., 1])
+            assert bool((jp >= expect_lo - 1e-6).all()) and bool((jp <= expect_hi + 1e-6).all())
+    assert bool(ever.any()) and not bool(ever.all())
+    assert bool((env.sim_writes["root_pose"][~ever] == 0).all())
+    env.close()
+
+
 @pytest.mark.parametrize("mode", ["fused-eager", "fused-graph", "generic-normalized"])
 def test_runner_learn_modes(mode, tmp_path):
     """OnPolicyRunner.learn through the three rollout paths (train.py:167-183 surface), checkpoint round trip."""

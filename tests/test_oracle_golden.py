@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from _util import TASKS, Golden, assert_close
+import os
+
+from _util import GOLDEN, TASKS, Golden, assert_close
 from oracle.mdp_oracle import OracleEnv
 
 
@@ -67,3 +69,34 @@ def test_math_helpers_match_reference():
         "scale_transform": m.scale_transform(v, torch.from_numpy(z["lower"]), torch.from_numpy(z["upper"])),
     }.items():
         assert torch.equal(got, torch.from_numpy(z[name])), name  # same ops, same machine: bit-exact
+
+
+def test_events_oracle_matches_reference():
+    """oracle/events_oracle.py against tests/golden/events.npz (real reference event terms + terrain curriculum)."""
+    import json
+
+    from oracle import events_oracle as eo
+
+    z = np.load(os.path.join(GOLDEN, "events.npz"))
+    meta = json.loads(str(z["meta"]))
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    mask = t("mask")
+    pose, vel = eo.reset_root_state_uniform(t("default_root_state"), t("env_origins"), meta["pose_range"], meta["velocity_range"],
+                                            t("root/u_pose"), t("root/u_vel"))
+    assert_close(pose[mask], t("root/pose_out")[mask], 1e-6, "root pose")
+    assert_close(vel[mask], t("root/vel_out")[mask], 1e-6, "root velocity")
+    for tag in ("scale", "scale2", "offset"):
+        r = z[f"joints_{tag}/ranges"]
+        p, v = eo.reset_joints(t("default_joint_pos"), t("default_joint_vel"), t("soft_joint_pos_limits"), t("soft_joint_vel_limits"),
+                               (float(r[0]), float(r[1])), (float(r[2]), float(r[3])), t(f"joints_{tag}/u_pos"), t(f"joints_{tag}/u_vel"),
+                               tag == "offset")
+        assert_close(p[mask], t(f"joints_{tag}/pos_out")[mask], 1e-6, f"joint pos {tag}")
+        assert_close(v[mask], t(f"joints_{tag}/vel_out")[mask], 1e-6, f"joint vel {tag}")
+    pv = eo.push_by_setting_velocity(t("root_vel_w"), meta["push_range"], t("push/u"))
+    assert_close(pv[mask], t("push/vel_out")[mask], 1e-6, "push")
+    lv, og, mean = eo.terrain_levels_vel(mask, t("curr/root_pos_w"), t("curr/env_origins_in"), t("curr/command"), t("curr/terrain_origins"),
+                                         t("curr/levels_in"), t("curr/types"), meta["terrain_size"], meta["max_episode_length_s"],
+                                         t("curr/randint"))
+    assert torch.equal(lv, t("curr/levels_out"))
+    assert torch.equal(og, t("curr/env_origins_out"))
+    assert abs(float(mean) - float(z["curr/mean_level"])) < 1e-6

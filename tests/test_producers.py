@@ -161,3 +161,112 @@ def test_empirical_normalization_matches_rsl_rl_restatement():
     m0 = norm._mean.clone()
     assert_close(norm(x.cuda()), orc.forward(x, training=False), 1e-5, "eval mode")
     assert torch.equal(norm._mean, m0)
+
+
+# ------------------------------------------------------------------------------------------------ reset events (8f row 2)
+def _events_golden():
+    import json
+
+    z = np.load(os.path.join(GOLDEN, "events.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.mark.gpu
+def test_reset_events_hip_matches_reference():
+    """imx_reset_events / imx_push_velocity fed the reference's uniform draws vs what the REAL reference terms wrote."""
+    from isaaclab_amd.events import ResetEvents
+
+    z, meta = _events_golden()
+    N, J = meta["N"], meta["J"]
+    c = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    mask = c("mask").to(torch.uint8)
+    mb = c("mask")
+    for tag, mode in (("scale", "scale"), ("scale2", "scale"), ("offset", "offset")):
+        r = z[f"joints_{tag}/ranges"]
+        ev = ResetEvents(N, J, "cuda", meta["pose_range"], meta["velocity_range"], (float(r[0]), float(r[1])), (float(r[2]), float(r[3])),
+                         mode, meta["push_range"])
+        U = torch.cat([c("root/u_pose"), c("root/u_vel"), c(f"joints_{tag}/u_pos"), c(f"joints_{tag}/u_vel")], dim=1).contiguous()
+        pose, vel = torch.full((N, 7), 7.0, device="cuda"), torch.full((N, 6), 7.0, device="cuda")
+        jp, jv = torch.full((N, J), 7.0, device="cuda"), torch.full((N, J), 7.0, device="cuda")
+        ev.reset(mask, c("default_root_state"), c("env_origins"), pose, vel, c("default_joint_pos"), c("default_joint_vel"),
+                 c("soft_joint_pos_limits"), c("soft_joint_vel_limits"), jp, jv, uniforms=U)
+        assert_close(pose[mb], c("root/pose_out")[mb], 1e-6, "root pose")
+        assert_close(vel[mb], c("root/vel_out")[mb], 1e-6, "root velocity")
+        assert_close(jp[mb], c(f"joints_{tag}/pos_out")[mb], 1e-6, f"joint pos {tag}")
+        assert_close(jv[mb], c(f"joints_{tag}/vel_out")[mb], 1e-6, f"joint vel {tag}")
+        for t in (pose, vel, jp, jv):  # rows of envs that did not reset are untouched
+            assert bool((t[~mb] == 7.0).all())
+    v = c("root_vel_w").clone()
+    ev.push(mask, v, uniforms=c("push/u"))
+    assert_close(v[mb], c("push/vel_out")[mb], 1e-6, "push")
+    assert torch.equal(v[~mb], c("root_vel_w")[~mb])
+
+
+@pytest.mark.gpu
+def test_reset_events_in_kernel_generator_properties():
+    """Performance mode (counter-based generator): samples inside the ranges, deterministic per (seed, step), fresh per step."""
+    from isaaclab_amd.events import ResetEvents
+
+    N, J = 4096, 12
+    g = torch.Generator().manual_seed(5)
+    drs = torch.zeros(N, 13)
+    drs[:, 3] = 1.0
+    drs[:, 2] = 0.6
+    drs, org = drs.cuda(), (torch.randn(N, 3, generator=g) * 5).cuda()
+    djp = (torch.rand(N, J, generator=g) + 0.5).cuda()
+    djv = torch.ones(N, J).cuda()
+    plim = torch.stack([torch.full((N, J), -10.0), torch.full((N, J), 10.0)], dim=-1).cuda()
+    vlim = torch.full((N, J), 0.5).cuda()
+    cfg = {"reset_base": {"func": "isaaclab.envs.mdp.events:reset_root_state_uniform", "mode": "reset",
+                          "params": {"pose_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-3.14, 3.14)},
+                                     "velocity_range": {"x": (-0.5, 0.5), "roll": (-0.2, 0.2)}}},
+           "reset_robot_joints": {"func": "isaaclab.envs.mdp.events:reset_joints_by_scale", "mode": "reset",
+                                  "params": {"position_range": (0.5, 1.5), "velocity_range": (-2.0, 2.0)}},
+           "push_robot": {"func": "isaaclab.envs.mdp.events:push_by_setting_velocity", "mode": "interval",
+                          "params": {"velocity_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5)}}}}
+    outs = []
+    for trial in range(2):
+        ev = ResetEvents.from_cfg(cfg, N, J, "cuda", seed=9)
+        pose, vel, jp, jv = (torch.zeros(N, 7, device="cuda"), torch.zeros(N, 6, device="cuda"), torch.zeros(N, J, device="cuda"),
+                             torch.zeros(N, J, device="cuda"))
+        ev.reset(None, drs, org, pose, vel, djp, djv, plim, vlim, jp, jv)
+        first = pose.clone()
+        ev.reset(None, drs, org, pose, vel, djp, djv, plim, vlim, jp, jv)
+        outs.append((first, pose.clone(), vel.clone(), jp.clone(), jv.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))  # same seed, same step sequence -> same samples
+    first, pose, vel, jp, jv = outs[0]
+    assert not torch.equal(first, pose)  # the step counter advanced
+    d = pose[:, :3] - org - drs[:, :3]
+    assert float(d[:, :2].abs().max()) <= 0.5 + 1e-6 and float(d[:, 2].abs().max()) <= 1e-6
+    assert 0.2 < float(d[:, 0].std()) < 0.35  # U(-0.5, 0.5): sigma = 0.289
+    assert_close(pose[:, 3:].norm(dim=1), torch.ones(N), 1e-5, "unit quaternion")
+    assert float(pose[:, 4:6].abs().max()) <= 1e-6  # yaw only
+    assert float(vel[:, 0].abs().max()) <= 0.5 and float(vel[:, 3].abs().max()) <= 0.2 and float(vel[:, [1, 2, 4, 5]].abs().max()) == 0.0
+    ratio = jp / djp
+    assert float(ratio.min()) >= 0.5 - 1e-6 and float(ratio.max()) <= 1.5 + 1e-6
+    assert float(jv.abs().max()) <= 0.5  # clamped to the soft velocity limit
+    v = torch.zeros(N, 6, device="cuda")
+    ev.push(None, v)
+    assert float(v[:, :2].abs().max()) <= 0.5 and float(v[:, 2:].abs().max()) == 0.0 and float(v[:, 0].std()) > 0.2
+
+
+@pytest.mark.gpu
+def test_terrain_curriculum_hip_matches_reference():
+    from isaaclab_amd.events import TerrainCurriculum
+
+    z, meta = _events_golden()
+    c = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    levels, origins = c("curr/levels_in").clone(), c("curr/env_origins_in").clone()
+    cur = TerrainCurriculum(c("curr/terrain_origins"), levels, c("curr/types"), origins, meta["terrain_size"], meta["max_episode_length_s"])
+    mean = cur.update(c("mask").to(torch.uint8), c("curr/root_pos_w"), c("curr/command"), rand_levels=c("curr/randint"))
+    assert torch.equal(levels, c("curr/levels_out"))
+    assert torch.equal(origins, c("curr/env_origins_out"))
+    assert abs(float(mean) - float(z["curr/mean_level"])) < 1e-6
+    # in-kernel draw for solved top levels: stays inside [0, R)
+    levels2 = torch.full_like(levels, meta["R"] - 1)
+    far = c("curr/env_origins_in").clone()
+    cur2 = TerrainCurriculum(c("curr/terrain_origins"), levels2, c("curr/types"), far.clone(), meta["terrain_size"], meta["max_episode_length_s"])
+    pos = far.clone()
+    pos[:, 0] += 5.0  # walked 5 m > half a tile: everyone moves up from the last level
+    cur2.update(None, pos, c("curr/command"))
+    assert int(levels2.min()) >= 0 and int(levels2.max()) < meta["R"] and len(torch.unique(levels2)) > 3
