@@ -223,6 +223,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): native libraries on the GPU box print to fd 1 while the device is
+    # initialised (libdrm's "amdgpu.ids: No such file or directory"), so fd 1 points at stderr until the final print
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -342,7 +348,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.task, args.num_envs, T, args.cpu_budget)
             out["env_step_path"]["vs_cpu_baseline"] = env_rate / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
