@@ -85,7 +85,10 @@ def test_wrapper_surface_and_time_outs():
 
 
 @pytest.mark.parametrize("task,N", [("Isaac-Velocity-Rough-Anymal-C-v0", 4096), ("Isaac-Velocity-Rough-G1-v0", 4096),
-                                    ("Isaac-Velocity-Flat-Anymal-C-v0", 100_003)])
+                                    ("Isaac-Velocity-Flat-Anymal-C-v0", 100_003),
+                                    # ragged / tiny batches: partial waves, a single env, one env past a 64-env block
+                                    ("Isaac-Velocity-Rough-Anymal-C-v0", 1), ("Isaac-Velocity-Rough-Anymal-C-v0", 63),
+                                    ("Isaac-Velocity-Flat-Anymal-C-v0", 65), ("Isaac-Cartpole-v0", 3)])
 def test_full_size_against_cpu_oracle(task, N):
     """BASELINE.json sizes: same seeded synthetic feed through the HIP path and the CPU oracle."""
     from isaaclab_amd.env import ManagerBasedRLEnv, load_task_cfg
@@ -129,7 +132,7 @@ def test_full_size_against_cpu_oracle(task, N):
             from oracle.mdp_oracle import quat_apply_yaw
             from oracle.raycast import raycast_f64
 
-            ne, R = 24, env.plan.num_rays
+            ne, R = min(24, N), env.plan.num_rays
             local = torch.from_numpy(env.plan.ray_starts_local).unsqueeze(0).repeat(ne, 1, 1)
             starts = quat_apply_yaw(cpu_feed["root_quat_w"][:ne].repeat(1, R), local) + cpu_feed["root_pos_w"][:ne].unsqueeze(1)
             dirs = torch.tensor(env.plan.ray_direction).repeat(ne * R, 1)
@@ -139,7 +142,7 @@ def test_full_size_against_cpu_oracle(task, N):
         out = orc.post_physics_step(u)
         assert torch.equal(term.cpu(), out["terminated"]) and torch.equal(tout.cpu(), out["time_outs"])
         assert torch.equal(env.reset_env_ids.cpu(), out["reset_env_ids"])
-        assert len(out["reset_env_ids"]) > 0
+        assert len(out["reset_env_ids"]) > 0 or (N < 97 and len(recorded) > 1)  # small batches: only env 0 is primed to time out, on the first step
         assert_close(rew, out["reward"], FLOAT_TOL, "reward")
         assert_close(obs_dict["policy"], out["obs"], FLOAT_TOL, "obs")
         assert torch.equal(env.episode_length_buf.cpu(), orc.episode_length_buf)
