@@ -239,7 +239,9 @@ int imx_gae(int64_t T, int64_t N, const float* rewards_d, const float* values_d,
  * minibatch of M samples with A action dims.  sigma_stride = A for a per-sample (M,A) std, 0 for the shared (A) std
  * parameter.  fwd writes out8 = {surrogate_loss, value_loss, entropy_mean, kl_mean, loss, -, -, -} with
  * loss = surrogate + value_loss_coef*value_loss - entropy_coef*entropy, and (optional) accum5 += {value_loss,
- * surrogate, entropy, kl, 1}; bwd writes grad_scale * d(loss)/d(mu), /d(sigma) (per sample, (M,A)), /d(value).
+ * surrogate, entropy, kl, 1}; bwd writes grad_scale * d(loss)/d(mu), /d(sigma) (per sample, (M,A)), /d(value); the policy
+ * part (dmu_d, dsigma_d) and the value part (dvalue_d) are independent: pass NULL for one to launch them separately
+ * (actor and critic then run forward -> loss gradient -> backward on their own streams without meeting).
  * PARITY UNPINNED (rsl_rl absent). */
 size_t imx_ppo_scratch_bytes(int64_t M);
 int imx_ppo_loss_fwd(int64_t M, int64_t A, const float* mu_d, const float* sigma_d, int64_t sigma_stride,

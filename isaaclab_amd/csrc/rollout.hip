@@ -214,28 +214,31 @@ k_ppo_bwd(int64_t M, int A, const float* __restrict__ mu, const float* __restric
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float inv_m = gscale / (float)M;
-    float logp = 0.0f;
-    for (int a = 0; a < A; ++a) {
-        const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
-        const float d = act[i * A + a] - m;
-        logp += -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI;
+    if (dmu) {  // policy part (the value part below is independent: the two may be launched separately)
+        float logp = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
+            const float d = act[i * A + a] - m;
+            logp += -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI;
+        }
+        const float ratio = expf(logp - old_logp[i]);
+        const float ad = adv[i];
+        const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+        // torch.max picks the first argument's gradient on ties? (max backward splits evenly on ties; ties only when
+        // ratio is inside the clip range where both branches have the same derivative -ad*ratio)
+        float dsur_dlogp;
+        if (s1 >= s2) dsur_dlogp = -ad * ratio;
+        else dsur_dlogp = (ratio > 1.0f - clip && ratio < 1.0f + clip) ? -ad * ratio : 0.0f;
+        const float g = dsur_dlogp * inv_m;
+        for (int a = 0; a < A; ++a) {
+            const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
+            const float d = act[i * A + a] - m;
+            dmu[i * A + a] = g * (d / (s * s));
+            // dlogp/ds = d^2/s^3 - 1/s ; dent/ds = 1/s
+            dsigma[i * A + a] = g * ((d * d) / (s * s * s) - 1.0f / s) - ecoef * inv_m / s;
+        }
     }
-    const float ratio = expf(logp - old_logp[i]);
-    const float ad = adv[i];
-    const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-    // torch.max picks the first argument's gradient on ties? (max backward splits evenly on ties; ties only when
-    // ratio is inside the clip range where both branches have the same derivative -ad*ratio)
-    float dsur_dlogp;
-    if (s1 >= s2) dsur_dlogp = -ad * ratio;
-    else dsur_dlogp = (ratio > 1.0f - clip && ratio < 1.0f + clip) ? -ad * ratio : 0.0f;
-    const float g = dsur_dlogp * inv_m;
-    for (int a = 0; a < A; ++a) {
-        const float m = mu[i * A + a], s = sigma[i * sigma_stride + a];
-        const float d = act[i * A + a] - m;
-        dmu[i * A + a] = g * (d / (s * s));
-        // dlogp/ds = d^2/s^3 - 1/s ; dent/ds = 1/s
-        dsigma[i * A + a] = g * ((d * d) / (s * s * s) - 1.0f / s) - ecoef * inv_m / s;
-    }
+    if (!dval) return;
     const float v = val[i], R = ret[i];
     float dv;
     if (clipped_value) {
@@ -276,8 +279,11 @@ extern "C" int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu, const flo
                                 float* dmu, float* dsigma, float* dval, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && A > 0, "imx_ppo_loss_bwd: bad sizes");
     IMX_REQUIRE(sigma_stride == 0 || sigma_stride == A, "imx_ppo_loss_bwd: sigma_stride must be 0 (shared std) or A");
-    IMX_REQUIRE(mu && sigma && act && old_logp && adv && ret && val && dmu && dsigma && dval, "imx_ppo_loss_bwd: null argument");
-    IMX_REQUIRE(!clipped_value || old_val, "imx_ppo_loss_bwd: clipped value loss needs old values");
+    IMX_REQUIRE(dmu || dval, "imx_ppo_loss_bwd: nothing to compute (dmu and dval are both null)");
+    IMX_REQUIRE(!dmu || (mu && sigma && act && old_logp && adv && dsigma), "imx_ppo_loss_bwd: the policy part needs mu, sigma, "
+                "actions, old log-prob, advantages and dsigma");
+    IMX_REQUIRE(!dval || (ret && val), "imx_ppo_loss_bwd: the value part needs returns and values");
+    IMX_REQUIRE(!dval || !clipped_value || old_val, "imx_ppo_loss_bwd: clipped value loss needs old values");
     hipLaunchKernelGGL(k_ppo_bwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, mu, sigma,
                        (int)sigma_stride, act, old_logp, adv, ret, val, old_val, clip, clipped_value, vcoef, ecoef, gscale, dmu,
                        dsigma, dval);

@@ -307,58 +307,67 @@ class PPO:
         stream = _lib.current_stream(self.device)
         M, A = actions.shape
         ws = self._workspace(M, A)
-        # actor and critic are independent until the loss: run the critic on a side stream so that the narrow layers
-        # (N = 128, 12, 1 columns: fewer tiles than CUs) of one network overlap with the other's
-        side = self._side_stream()
-        main = torch.cuda.current_stream(self.device)
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                value, saved_c = mlp_forward(self._critic_layers, critic_obs)
-            mu, saved_a = mlp_forward(self._actor_layers, obs)
-            main.wait_stream(side)
-            value.record_stream(main)  # allocated on the side stream, consumed by the loss kernels on the main stream
-        else:
-            mu, saved_a = mlp_forward(self._actor_layers, obs)
-            value, saved_c = mlp_forward(self._critic_layers, critic_obs)
         if pol.noise_std_type == "scalar":
             sigma, sstride = pol.std, 0
         else:
-            sigma, sstride = torch.exp(pol.log_std).expand_as(mu).contiguous(), A
-        # the gradients need only the per-sample terms: loss_bwd first, then the backward GEMMs; the loss values / KL
-        # (logging, adaptive LR) and the sigma-gradient reduction run beside them on a third stream
-        check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
-                                 advantages.data_ptr(), returns.data_ptr(), value.data_ptr(), target_values.data_ptr(),
-                                 float(self.clip_param), int(self.use_clipped_value_loss), float(self.value_loss_coef),
-                                 float(self.entropy_coef), 1.0, ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(),
-                                 ws["dvalue"].data_ptr(), stream))
+            sigma, sstride = None, A  # expanded below, once mu exists
+        clipf, vclip = float(self.clip_param), int(self.use_clipped_value_loss)
+        vcoef, ecoef = float(self.value_loss_coef), float(self.entropy_coef)
 
-        def loss_values(st):
+        def actor_pass(st):
+            nonlocal sigma
+            mu, saved_a = mlp_forward(self._actor_layers, obs)
+            if sigma is None:
+                sigma = torch.exp(pol.log_std).expand_as(mu).contiguous()
+            check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
+                                     advantages.data_ptr(), None, None, None, clipf, vclip, vcoef, ecoef, 1.0,
+                                     ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(), None, st))
+            return mu, saved_a
+
+        def critic_pass(st):
+            value, saved_c = mlp_forward(self._critic_layers, critic_obs)
+            check(L.imx_ppo_loss_bwd(M, A, None, None, sstride, None, None, None, returns.data_ptr(), value.data_ptr(),
+                                     target_values.data_ptr(), clipf, vclip, vcoef, ecoef, 1.0, None, None, ws["dvalue"].data_ptr(), st))
+            return value, saved_c
+
+        def loss_values(mu, value, st):  # logging / adaptive-LR inputs and the sigma gradient: off the critical path
             check(L.imx_ppo_loss_fwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
                                      old_mu.data_ptr(), old_sigma.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
-                                     value.data_ptr(), target_values.data_ptr(), float(self.clip_param),
-                                     int(self.use_clipped_value_loss), float(self.value_loss_coef), float(self.entropy_coef),
+                                     value.data_ptr(), target_values.data_ptr(), clipf, vclip, vcoef, ecoef,
                                      self._out8.data_ptr(), self._stats.data_ptr(), ws["scratch"].data_ptr(), st))
             if pol.noise_std_type == "scalar":
                 torch.sum(ws["dsigma"], dim=0, out=pol.std.grad)
             else:
                 torch.sum(ws["dsigma"] * sigma, dim=0, out=pol.log_std.grad)
 
+        # The policy gradient needs only mu, the value gradient only the critic's output: actor and critic run
+        # forward -> loss gradient -> backward on two streams and meet once, at the end of the minibatch.  The loss
+        # VALUES (logging, KL for the adaptive LR) need both heads and run on a third stream beside the backward GEMMs.
+        side = self._side_stream()
+        main = torch.cuda.current_stream(self.device)
         if side is not None:
             aux = self._aux_stream()
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                loss_values(aux.cuda_stream)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                value, saved_c = critic_pass(side.cuda_stream)
+                value_ready = torch.cuda.Event()
+                value_ready.record(side)
                 mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
+            mu, saved_a = actor_pass(stream)
+            aux.wait_stream(main)
+            aux.wait_event(value_ready)
+            with torch.cuda.stream(aux):
+                loss_values(mu, value, aux.cuda_stream)
             mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             main.wait_stream(side)
             main.wait_stream(aux)
             mu.record_stream(aux)
             value.record_stream(aux)
+            value.record_stream(main)
         else:
-            loss_values(stream)
+            mu, saved_a = actor_pass(stream)
+            value, saved_c = critic_pass(stream)
+            loss_values(mu, value, stream)
             mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
         self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
