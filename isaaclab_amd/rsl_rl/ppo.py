@@ -380,13 +380,25 @@ class PPO:
         stream = _lib.current_stream(self.device)
         self._stats.zero_()
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
-        gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
-        for batch in gen:
+        side = self._side_stream()
+        copy_stream = self._aux_stream() if side is not None else None
+        main = torch.cuda.current_stream(self.device) if side is not None else None
+        gen = iter(self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, copy_stream=copy_stream))
+        item = next(gen, None)
+        while item is not None:
+            if copy_stream is not None:
+                batch, ready = item
+                main.wait_event(ready)
+            else:
+                batch = item
             if self.normalize_advantage_per_mini_batch:
                 batch = list(batch)
                 adv = batch[4]
                 batch[4] = (adv - adv.mean()) / (adv.std() + 1e-8)
             self.minibatch_step(*batch)
+            # the next minibatch's gather (HBM-bound) is issued now, on the third stream: it starts when the backward pass
+            # has finished with the buffers and runs beside the all-reduce / norm / Adam kernels below
+            item = next(gen, None)
             if self.is_multi_gpu:
                 self.reduce_parameters()
             g = b.grad[:b.numel]
@@ -395,6 +407,8 @@ class PPO:
                                     self._adam.data_ptr(), b.grad[-1:].data_ptr() if adaptive else None,
                                     float(self.desired_kl or 0.0), _lib.ptr(norm), float(self.max_grad_norm or 0.0),
                                     self.betas[0], self.betas[1], self.eps, stream))
+        if copy_stream is not None:
+            main.wait_stream(copy_stream)
         self.storage.clear()
         return self._stats  # device tensor; .tolist() only when the caller wants to log
 

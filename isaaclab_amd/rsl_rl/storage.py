@@ -95,10 +95,13 @@ class RolloutStorage:
         gae_returns(self.rewards, self.values, self.dones, last_values.contiguous(), gamma, lam, normalize_advantage,
                     self.returns, self.advantages, self._gae_scratch)
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8, copy_stream=None):
         """Yields (obs, critic_obs, actions, values, advantages, returns, old_log_prob, old_mu, old_sigma) minibatches
         of a random permutation of the T*N transitions; the nine gathers are ONE ``imx_gather_rows`` launch into
-        reusable buffers (valid until the next minibatch is requested)."""
+        reusable buffers (valid until the next minibatch is requested).  With ``copy_stream`` the gather is issued on
+        that stream (after everything enqueued on the current stream so far) and ``(batch, ready_event)`` is yielded: the
+        caller requests the next minibatch right after the backward pass and waits for ``ready_event`` only before it
+        uses the data, so the HBM-bound gather runs beside the optimiser step instead of in front of the next forward."""
         import ctypes
 
         batch_size = self.num_envs * self.num_transitions_per_env
@@ -121,11 +124,18 @@ class RolloutStorage:
         widths = (ctypes.c_int32 * n)(*[s.shape[1] for s in srcs])
         L = lib()
         stream = _lib.current_stream(torch.device(self.device))
+        main = torch.cuda.current_stream(torch.device(self.device)) if copy_stream is not None else None
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 idx = indices[i * M:(i + 1) * M]
+                if copy_stream is not None:
+                    copy_stream.wait_stream(main)
+                    stream = copy_stream.cuda_stream
                 check(L.imx_gather_rows(M, idx.data_ptr(), n, src_p, dst_p, widths, stream))
-                if self.privileged_observations is not None:
-                    yield tuple(dst)
+                batch = tuple(dst) if self.privileged_observations is not None else (dst[0], dst[0]) + tuple(dst[1:])
+                if copy_stream is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
+                    yield batch, ready
                 else:
-                    yield (dst[0], dst[0]) + tuple(dst[1:])
+                    yield batch
