@@ -346,19 +346,23 @@ class PPO:
         side = self._side_stream()
         main = torch.cuda.current_stream(self.device)
         if side is not None:
+            # Issue order matters as much as the streams: the host needs ~8 us per launch, so the two networks are fed
+            # alternately (forward, forward, backward, backward) -- enqueueing one network's ~30 launches first would
+            # leave the other stream empty for the first 200 us of every minibatch.
             aux = self._aux_stream()
             side.wait_stream(main)
+            mu, saved_a = actor_pass(stream)
             with torch.cuda.stream(side):
                 value, saved_c = critic_pass(side.cuda_stream)
                 value_ready = torch.cuda.Event()
                 value_ready.record(side)
-                mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
-            mu, saved_a = actor_pass(stream)
             aux.wait_stream(main)
             aux.wait_event(value_ready)
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
+            with torch.cuda.stream(side):
+                mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
             with torch.cuda.stream(aux):
                 loss_values(mu, value, aux.cuda_stream)
-            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             main.wait_stream(side)
             main.wait_stream(aux)
             mu.record_stream(aux)
