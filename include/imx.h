@@ -270,6 +270,14 @@ int imx_adam_update(int64_t n, float* param_d, const float* grad_d, float* exp_a
                     const float* kl_d, float desired_kl, const float* grad_norm_d, float max_norm, float beta1,
                     float beta2, float eps, imx_stream_t stream);
 
+/* Same, with clip_grad_norm_'s total norm computed inside (one launch does the norm reduction, the adaptive-KL rule and
+ * the step bookkeeping; state8[7] receives the norm).  max_norm <= 0 disables clipping.  scratch_d:
+ * imx_adam_norm_scratch_bytes(n) bytes, ZERO-filled once by the caller (the kernel re-arms its ticket). */
+size_t imx_adam_norm_scratch_bytes(int64_t n);
+int imx_adam_update_norm(int64_t n, float* param_d, const float* grad_d, float* exp_avg_d, float* exp_avg_sq_d, float* state8_d,
+                         const float* kl_d, float desired_kl, float max_norm, float beta1, float beta2, float eps,
+                         void* scratch_d, size_t scratch_bytes, imx_stream_t stream);
+
 /* rsl_rl RolloutStorage.mini_batch_generator: dst[k][r, :] = src[k][idx[r], :] for n <= 12 fp32 arrays of
  * width_floats[k] columns, one launch.  src_d / dst_d / width_floats are HOST arrays of device pointers / widths. */
 int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,

@@ -350,6 +350,61 @@ __global__ void k_adam_prepare(float* __restrict__ st, const float* __restrict__
     st[6] = sqrtf(1.0f - p2);
 }
 
+// clip_grad_norm_'s total norm + the schedule above in ONE launch: every block sums the squares of its slice in a fixed
+// order, the last block to finish (agent-scope release / acquire around a ticket) adds the partials in block order and
+// runs k_adam_prepare's arithmetic.  Replaces torch.linalg.vector_norm (a fill + a reduce kernel) + k_adam_prepare.
+// scratch: [0, G) partial sums, [G] ticket (must be zero on entry; the last block re-arms it).
+constexpr int ADAM_NORM_BLOCK = 256, ADAM_NORM_PER_THREAD = 16;
+__global__ void __launch_bounds__(ADAM_NORM_BLOCK)
+k_adam_norm_prepare(int64_t n, const float* __restrict__ g, float* __restrict__ st, const float* __restrict__ kl_d, float desired_kl,
+                    float max_norm, float b1, float b2, float* __restrict__ scratch) {
+    __shared__ float red[ADAM_NORM_BLOCK];
+    __shared__ bool last;
+    const int G = gridDim.x;
+    const int64_t base = (int64_t)blockIdx.x * ADAM_NORM_BLOCK * ADAM_NORM_PER_THREAD;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ADAM_NORM_PER_THREAD; ++k) {
+        const int64_t i = base + (int64_t)k * ADAM_NORM_BLOCK + threadIdx.x;
+        if (i < n) s += g[i] * g[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = ADAM_NORM_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(scratch + G);
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = red[0];
+        __atomic_thread_fence(__ATOMIC_RELEASE);  // agent scope: the partial is visible before the ticket
+        const unsigned int t = atomicAdd(ticket, 1u);
+        last = (t == (unsigned int)G - 1u);
+        if (last) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    float tot = 0.0f;
+    for (int b = 0; b < G; ++b) tot += __builtin_nontemporal_load(scratch + b);
+    *ticket = 0u;
+    const float norm = sqrtf(tot);
+    float lr = st[0];
+    if (kl_d) {
+        const float kl = kl_d[0];
+        if (kl > desired_kl * 2.0f) lr = fmaxf(1.0e-5f, lr / 1.5f);
+        else if (kl < desired_kl / 2.0f && kl > 0.0f) lr = fminf(1.0e-2f, lr * 1.5f);
+    }
+    const float p1 = st[2] * b1, p2 = st[3] * b2;
+    st[0] = lr;
+    st[1] += 1.0f;
+    st[2] = p1;
+    st[3] = p2;
+    st[4] = max_norm > 0.0f ? fminf(max_norm / (norm + 1.0e-6f), 1.0f) : 1.0f;
+    st[5] = lr / (1.0f - p1);
+    st[6] = sqrtf(1.0f - p2);
+    st[7] = norm;
+}
+
 __global__ void __launch_bounds__(256)
 k_adam_apply(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
              const float* __restrict__ st, float b1, float b2, float eps) {
@@ -370,6 +425,28 @@ extern "C" int imx_adam_update(int64_t n, float* p, const float* g, float* m, fl
     IMX_REQUIRE(n > 0 && p && g && m && v && state8, "imx_adam_update: bad arguments");
     hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, state8, kl_d, desired_kl, grad_norm_d,
                        max_norm, beta1, beta2);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_adam_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (const float*)state8, beta1,
+                       beta2, eps);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+
+static int adam_norm_blocks(int64_t n) {
+    return (int)((n + (int64_t)ADAM_NORM_BLOCK * ADAM_NORM_PER_THREAD - 1) / ((int64_t)ADAM_NORM_BLOCK * ADAM_NORM_PER_THREAD));
+}
+
+extern "C" size_t imx_adam_norm_scratch_bytes(int64_t n) { return n > 0 ? ((size_t)adam_norm_blocks(n) + 1) * sizeof(float) : 0; }
+
+extern "C" int imx_adam_update_norm(int64_t n, float* p, const float* g, float* m, float* v, float* state8, const float* kl_d,
+                                    float desired_kl, float max_norm, float beta1, float beta2, float eps, void* scratch_d,
+                                    size_t scratch_bytes, imx_stream_t stream) {
+    IMX_REQUIRE(n > 0 && p && g && m && v && state8 && scratch_d, "imx_adam_update_norm: bad arguments");
+    const int G = adam_norm_blocks(n);
+    IMX_REQUIRE(scratch_bytes >= ((size_t)G + 1) * sizeof(float), "imx_adam_update_norm: scratch too small (see imx_adam_norm_scratch_bytes)");
+    hipLaunchKernelGGL(k_adam_norm_prepare, dim3((unsigned)G), dim3(ADAM_NORM_BLOCK), 0, (hipStream_t)stream, n, g, state8, kl_d, desired_kl,
+                       max_norm, beta1, beta2, (float*)scratch_d);
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_adam_apply, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (const float*)state8, beta1,
                        beta2, eps);

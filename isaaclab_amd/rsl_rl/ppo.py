@@ -215,7 +215,7 @@ class PPO:
         else:
             self.gpu_global_rank, self.gpu_world_size = 0, 1
         self.policy = policy.to(self.device)
-        self.bucket = FlatParams(self.policy)
+        self.bucket = FlatParams(self.policy, extra_slots=8)  # trailing slots = the 8 loss scalars (KL among them)
         self.storage: RolloutStorage | None = None
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
@@ -227,7 +227,12 @@ class PPO:
         # device-side optimiser state: [lr, step, beta1^t, beta2^t, clip coef, lr/bias1, sqrt(bias2), -]
         self._adam = torch.tensor([float(learning_rate), 0.0, 1.0, 1.0, 1.0, 0.0, 1.0, 0.0], device=self.device)
         self._stats = torch.zeros(5, device=self.device)  # running sums: value, surrogate, entropy, kl, count
-        self._out8 = torch.zeros(8, device=self.device)
+        # imx_ppo_loss_fwd writes {surrogate, value loss, entropy, KL, loss, -, -, -} straight behind the gradients: the KL
+        # estimate rides in the gradient bucket's all-reduce without a copy
+        self._out8 = self.bucket.grad[self.bucket.numel:self.bucket.numel + 8]
+        self._kl = self._out8[3:4]
+        self._norm_scratch = torch.zeros(int(lib().imx_adam_norm_scratch_bytes(self.bucket.numel)), dtype=torch.uint8, device=self.device) \
+            if self.device.type == "cuda" else None
         self._actor_layers = _mlp_layers(self.policy.actor)
         self._critic_layers = _mlp_layers(self.policy.critic)
         self._ws: dict = {}
@@ -374,7 +379,6 @@ class PPO:
             loss_values(mu, value, stream)
             mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
             mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
-        self.bucket.grad[-1:].copy_(self._out8[3:4])  # KL estimate rides in the gradient bucket
         return self._out8
 
     @torch.no_grad()
@@ -405,12 +409,12 @@ class PPO:
             item = next(gen, None)
             if self.is_multi_gpu:
                 self.reduce_parameters()
-            g = b.grad[:b.numel]
-            norm = torch.linalg.vector_norm(g).reshape(1) if self.max_grad_norm is not None else None
-            check(L.imx_adam_update(b.numel, b.flat.data_ptr(), g.data_ptr(), b.exp_avg.data_ptr(), b.exp_avg_sq.data_ptr(),
-                                    self._adam.data_ptr(), b.grad[-1:].data_ptr() if adaptive else None,
-                                    float(self.desired_kl or 0.0), _lib.ptr(norm), float(self.max_grad_norm or 0.0),
-                                    self.betas[0], self.betas[1], self.eps, stream))
+            # clip_grad_norm_ + adaptive-KL learning rate + Adam: two launches (norm reduction with the schedule in its
+            # last block, then the parameter update), all scalars on the device
+            check(L.imx_adam_update_norm(b.numel, b.flat.data_ptr(), b.grad.data_ptr(), b.exp_avg.data_ptr(), b.exp_avg_sq.data_ptr(),
+                                         self._adam.data_ptr(), self._kl.data_ptr() if adaptive else None,
+                                         float(self.desired_kl or 0.0), float(self.max_grad_norm or 0.0), self.betas[0],
+                                         self.betas[1], self.eps, self._norm_scratch.data_ptr(), self._norm_scratch.numel(), stream))
         if copy_stream is not None:
             main.wait_stream(copy_stream)
         self.storage.clear()

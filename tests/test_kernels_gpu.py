@@ -171,7 +171,7 @@ def test_explicit_backward_matches_autograd(libimx):
     err = (got[:n] - ref).abs().max() / ref.abs().max()
     assert float(err) < 1e-5, f"flat gradient bucket: max err / max |g| = {float(err):.2e}"  # fp32 GEMM summation order
     assert_close(got[:n], ref, 1e-5, "flat gradient bucket")
-    assert abs(float(got[n]) - float(kl)) < 1e-6  # KL rides in the trailing slot
+    assert abs(float(got[n + 3]) - float(kl)) < 1e-6  # the loss scalars (KL = slot 3) ride behind the gradients
 
 
 @pytest.mark.parametrize("M,N,K", [(24576, 512, 235), (1000, 256, 512), (4099, 128, 256), (333, 130, 37), (5, 64, 48)])
@@ -239,19 +239,25 @@ def test_mlp_head_matches_autograd(libimx, M, K, A):
     assert libimx.imx_mlp_head_fwd(M, K, 17, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st) != 0
 
 
-def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx):
+@pytest.mark.parametrize("fused_norm", [False, True])
+def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx, fused_norm):
+    """imx_adam_update (norm supplied) and imx_adam_update_norm (norm reduced in-kernel, last-block schedule) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam + the upstream adaptive-KL rule."""
     from isaaclab_amd import _lib
 
-    n = 10_007
+    n = 10_007 if not fused_norm else 571_801
     g0 = torch.Generator().manual_seed(1)
     p = torch.randn(n, generator=g0).cuda()
     ref_p = torch.nn.Parameter(p.clone())
     opt = torch.optim.Adam([ref_p], lr=1e-3)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     state = torch.tensor([1e-3, 0, 1, 1, 1, 0, 1, 0], dtype=torch.float32, device="cuda")
+    nb = int(libimx.imx_adam_norm_scratch_bytes(n))
+    scratch = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
     lr_ref = 1e-3
     for step, kl in enumerate([0.004, 0.03, 0.012, 0.0, 0.05, 0.001]):
-        grad = (torch.randn(n, generator=g0) * (3.0 if step % 2 else 0.01)).cuda()
+        grad = (torch.randn(n, generator=g0) * (3.0 if step % 2 else 0.01) / (n / 10_007) ** 0.5).cuda()
         ref_p.grad = grad.clone()
         # upstream order: LR decision from KL, then clip, then step
         if kl > 0.02: lr_ref = max(1e-5, lr_ref / 1.5)
@@ -261,9 +267,13 @@ def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx):
         opt.step()
         norm = torch.linalg.vector_norm(grad).reshape(1)
         kl_t = torch.tensor([kl], device="cuda")
-        _lib.check(libimx.imx_adam_update(n, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(),
-                                          kl_t.data_ptr(), 0.01, norm.data_ptr(), 1.0, 0.9, 0.999, 1e-8,
-                                          torch.cuda.current_stream().cuda_stream))
+        if fused_norm:
+            _lib.check(libimx.imx_adam_update_norm(n, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(),
+                                                   kl_t.data_ptr(), 0.01, 1.0, 0.9, 0.999, 1e-8, scratch.data_ptr(), nb, st))
+            assert abs(float(state[7]) - float(norm)) <= 2e-6 * float(norm)  # the norm it clipped with
+        else:
+            _lib.check(libimx.imx_adam_update(n, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), state.data_ptr(),
+                                              kl_t.data_ptr(), 0.01, norm.data_ptr(), 1.0, 0.9, 0.999, 1e-8, st))
         assert abs(float(state[0]) - lr_ref) < 1e-9 and int(state[1]) == step + 1
         assert_close(p, ref_p.detach(), 1e-5, f"adam step {step}")
 
