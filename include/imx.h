@@ -353,6 +353,14 @@ size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_features);
 int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
                float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream);
 
+/* Same with the ELU backward of this layer fused in: dH_d is the gradient w.r.t. the layer's ACTIVATED output h = ELU(z),
+ * H_d that saved output; dZ = dH * (h > 0 ? 1 : h + elu_alpha) (aten elu_backward with is_result) is formed on the way
+ * into LDS -- no separate elementwise pass -- and written to dZ_out_d (M,N; may be NULL when no layer below needs it; must
+ * not alias dH_d); dW = dZ^T X, db = colsum(dZ). */
+int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_t ldg, const float* H_d, int64_t ldh, float elu_alpha,
+                   float* dZ_out_d, int64_t ldd, const float* X_d, int64_t ldx, float* dW_d, float* db_d, void* scratch_d,
+                   size_t scratch_bytes, imx_stream_t stream);
+
 /* Output layer forward, A <= 16 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K). */
 int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
                      imx_stream_t stream);

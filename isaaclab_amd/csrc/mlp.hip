@@ -36,6 +36,13 @@ struct DwArgs {
     float* part_db;  // [S][N] or null
     int tn, tk, S;
     int64_t rps;     // rows (samples) per split, multiple of DW_BM
+    // ACT variant: dY holds the gradient w.r.t. the layer's ACTIVATED output; the movers multiply it by ELU'(H) (H = the saved
+    // output, aten elu_backward with is_result) on its way into LDS and the first column tile writes the product to Dout
+    const float* H;
+    int64_t ldh;
+    float* Dout;
+    int64_t ldd;
+    float alpha;
 };
 
 // row of a 32x32 MFMA accumulator register: lanes 0-31 hold rows {0-3, 8-11, 16-19, 24-27}, lanes 32-63 the others
@@ -85,7 +92,28 @@ __device__ __forceinline__ void dw_store(const float (&r)[16], float* __restrict
 // stage ahead, registers -> the other LDS buffer).  One barrier per stage; the movers' ~1000 cycles of address
 // arithmetic, predicated loads and LDS writes run on the issue slots the 4096-cycle MFMA stream leaves free, instead of
 // in front of it (a single-role kernel measured 58 % of the f32 MFMA peak in its main loop for exactly that reason).
-template <bool YVEC, bool XVEC>
+template <bool VEC>
+__device__ __forceinline__ void dw_store_global(const float (&r)[16], float* __restrict__ dst, int64_t ld, int64_t row0, int64_t row_end,
+                                                int col0, int ncols, int t) {
+    if (VEC) {
+        const int c = col0 + 4 * (t & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + (t >> 5) + 8 * i;
+            if (row < row_end && c < ncols)
+                *reinterpret_cast<float4*>(dst + row * ld + c) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+        }
+    } else {
+        const int c = col0 + (t & 127);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = row0 + (t >> 7) + 2 * i;
+            if (row < row_end && c < ncols) dst[row * ld + c] = r[i];
+        }
+    }
+}
+
+template <bool YVEC, bool XVEC, bool ACT>
 __global__ void __launch_bounds__(512, 1) k_mlp_dw(DwArgs a) {
     __shared__ float sY[2][DW_BM * DW_LD];
     __shared__ float sX[2][DW_BM * DW_LD];
@@ -109,14 +137,23 @@ __global__ void __launch_bounds__(512, 1) k_mlp_dw(DwArgs a) {
     if (threadIdx.x >= 256) {
         // ------------------------------------------------------------------------------------------------ movers
         const int t = threadIdx.x - 256;
-        float ry[16], rx[16];
+        float ry[16], rx[16], rh[ACT ? 16 : 1];
         float dbv[4] = {0.f, 0.f, 0.f, 0.f};  // column sums of the dY slab (YVEC: 4 columns x rows t>>5 + 8i; else 1 column)
+        int64_t loaded_row0 = 0;
+        const bool write_d = ACT && a.Dout != nullptr && (tile % a.tk) == 0;
         auto load = [&](int st) {
             const int64_t row0 = m_begin + (int64_t)st * DW_BM;  // rows >= m_end load as zeros
+            loaded_row0 = row0;
             dw_load<YVEC>(ry, a.dY, a.ldy, row0, m_end, n0, a.N, t);
+            if constexpr (ACT) dw_load<YVEC>(rh, a.H, a.ldh, row0, m_end, n0, a.N, t);
             dw_load<XVEC>(rx, a.X, a.ldx, row0, m_end, k0, a.K, t);
         };
         auto store = [&](int buf) {
+            if constexpr (ACT) {  // gradient through ELU from its saved output: y > 0 ? 1 : y + alpha
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ry[q] *= rh[q] > 0.0f ? 1.0f : rh[q] + a.alpha;
+                if (write_d) dw_store_global<YVEC>(ry, a.Dout, a.ldd, loaded_row0, m_end, n0, a.N, t);
+            }
             dw_store<YVEC>(ry, sY[buf], t);
             dw_store<XVEC>(rx, sX[buf], t);
             if (want_db) {
@@ -394,33 +431,62 @@ extern "C" size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_feat
     return std::max(dw, head) + 256;
 }
 
-extern "C" int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
-                          float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream) {
-    IMX_REQUIRE(M > 0 && N > 0 && K > 0 && dY_d && X_d && dW_d && scratch_d, "imx_mlp_dw: bad arguments");
-    IMX_REQUIRE(ldy >= N && ldx >= K, "imx_mlp_dw: row pitch smaller than the row (ldy=%lld N=%d, ldx=%lld K=%d)", (long long)ldy, N,
+static int mlp_dw_launch(const char* who, int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* H_d, int64_t ldh,
+                         float alpha, float* Dout_d, int64_t ldd, const float* X_d, int64_t ldx, float* dW_d, float* db_d,
+                         void* scratch_d, size_t scratch_bytes, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && N > 0 && K > 0 && dY_d && X_d && dW_d && scratch_d, "%s: bad arguments", who);
+    IMX_REQUIRE(ldy >= N && ldx >= K, "%s: row pitch smaller than the row (ldy=%lld N=%d, ldx=%lld K=%d)", who, (long long)ldy, N,
                 (long long)ldx, K);
+    const bool act = H_d != nullptr;
+    IMX_REQUIRE(!act || (ldh >= N && (!Dout_d || ldd >= N)), "%s: activation / output pitch smaller than the row", who);
+    IMX_REQUIRE(!act || Dout_d != dY_d, "%s: d_out must not alias the incoming gradient (other tiles still read it)", who);
     const DwPlan p = dw_plan(M, N, K);
     const size_t need = ((size_t)p.S * N * K + (size_t)p.S * N) * sizeof(float);
-    IMX_REQUIRE(scratch_bytes >= need, "imx_mlp_dw: scratch too small (%zu < %zu bytes; see imx_mlp_scratch_bytes)", scratch_bytes, need);
+    IMX_REQUIRE(scratch_bytes >= need, "%s: scratch too small (%zu < %zu bytes; see imx_mlp_scratch_bytes)", who, scratch_bytes, need);
     DwArgs a;
     a.M = M; a.N = N; a.K = K;
     a.dY = dY_d; a.ldy = ldy; a.X = X_d; a.ldx = ldx;
     a.part = (float*)scratch_d;
     a.part_db = db_d ? a.part + (size_t)p.S * N * K : nullptr;
     a.tn = p.tn; a.tk = p.tk; a.S = p.S; a.rps = p.rps;
-    const bool yvec = (N % 4 == 0) && (ldy % 4 == 0) && aligned16(dY_d);
+    a.H = H_d; a.ldh = ldh; a.Dout = Dout_d; a.ldd = ldd; a.alpha = alpha;
+    bool yvec = (N % 4 == 0) && (ldy % 4 == 0) && aligned16(dY_d);
+    if (act) yvec = yvec && (ldh % 4 == 0) && aligned16(H_d) && (!Dout_d || ((ldd % 4 == 0) && aligned16(Dout_d)));
     const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X_d);
     const dim3 grid((unsigned)(p.tn * p.tk * p.S)), block(512);
     hipStream_t st = (hipStream_t)stream;
-    if (yvec && xvec) hipLaunchKernelGGL((k_mlp_dw<true, true>), grid, block, 0, st, a);
-    else if (yvec) hipLaunchKernelGGL((k_mlp_dw<true, false>), grid, block, 0, st, a);
-    else if (xvec) hipLaunchKernelGGL((k_mlp_dw<false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_dw<false, false>), grid, block, 0, st, a);
+#define IMX_DW_LAUNCH(Y, X, A) hipLaunchKernelGGL((k_mlp_dw<Y, X, A>), grid, block, 0, st, a)
+    if (act) {
+        if (yvec && xvec) IMX_DW_LAUNCH(true, true, true);
+        else if (yvec) IMX_DW_LAUNCH(true, false, true);
+        else if (xvec) IMX_DW_LAUNCH(false, true, true);
+        else IMX_DW_LAUNCH(false, false, true);
+    } else {
+        if (yvec && xvec) IMX_DW_LAUNCH(true, true, false);
+        else if (yvec) IMX_DW_LAUNCH(true, false, false);
+        else if (xvec) IMX_DW_LAUNCH(false, true, false);
+        else IMX_DW_LAUNCH(false, false, false);
+    }
+#undef IMX_DW_LAUNCH
     IMX_HIP(hipGetLastError());
     const int64_t total = (int64_t)N * K, threads = total + (db_d ? N : 0);
     hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((threads + 63) / 64)), dim3(64, RED_Y), 0, st, total, p.S, a.part, dW_d, N, a.part_db, db_d);
     IMX_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
+                          float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream) {
+    return mlp_dw_launch("imx_mlp_dw", M, N, K, dY_d, ldy, nullptr, 0, 0.0f, nullptr, 0, X_d, ldx, dW_d, db_d, scratch_d, scratch_bytes,
+                         stream);
+}
+
+extern "C" int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_t ldg, const float* H_d, int64_t ldh, float elu_alpha,
+                              float* dZ_out_d, int64_t ldd, const float* X_d, int64_t ldx, float* dW_d, float* db_d, void* scratch_d,
+                              size_t scratch_bytes, imx_stream_t stream) {
+    IMX_REQUIRE(H_d, "imx_mlp_dw_elu: the saved activation output is required");
+    return mlp_dw_launch("imx_mlp_dw_elu", M, N, K, dH_d, ldg, H_d, ldh, elu_alpha, dZ_out_d, ldd, X_d, ldx, dW_d, db_d, scratch_d,
+                         scratch_bytes, stream);
 }
 
 extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,

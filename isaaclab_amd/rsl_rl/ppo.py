@@ -164,32 +164,45 @@ def mlp_forward(layers, x, out=None):
 def mlp_backward(layers, saved, dout, scratch=None):
     """Writes dW/db of every layer straight into ``param.grad`` (views of the flat bucket).  dW / db: ``imx_mlp_dw``
     (split over the samples on the f32 MFMA); output layer: ``imx_mlp_head_bwd`` (dW, db, dX and the ELU' of the layer
-    below in one pass); the wide dX GEMMs stay in the library."""
+    below in one pass); the wide dX GEMMs stay in the library, and the ELU backward of a hidden layer is folded into that
+    layer's ``imx_mlp_dw_elu`` (no separate elementwise pass)."""
     L = lib()
-    d = dout
-    M = d.shape[0]
+    M = dout.shape[0]
     if scratch is None:
-        scratch = mlp_scratch(layers, M, d.device)
-    stream = _lib.current_stream(d.device)
+        scratch = mlp_scratch(layers, M, dout.device)
+    stream = _lib.current_stream(dout.device)
+    d = dout          # gradient w.r.t. the pre-activation output of layer i ...
+    pending = None    # ... or (gradient w.r.t. its ELU output, that output, alpha): resolved inside imx_mlp_dw_elu
     for i in range(len(layers) - 1, -1, -1):
         lin, _ = layers[i]
         x = saved[i] if not isinstance(saved[i], tuple) else saved[i][1]
         prev_act = layers[i - 1][1] if i > 0 else None
-        if not d.is_contiguous():
-            d = d.contiguous()
-        if i > 0 and _is_head(lin, x) and (prev_act is None or isinstance(prev_act, nn.ELU)):
-            dprev = torch.empty(M, lin.in_features, device=d.device, dtype=d.dtype)
-            check(L.imx_mlp_head_bwd(M, lin.in_features, lin.out_features, d.data_ptr(), x.data_ptr(), x.stride(0),
-                                     lin.weight.data_ptr(), float(prev_act.alpha) if prev_act is not None else 0.0,
-                                     int(prev_act is not None), dprev.data_ptr(), lin.weight.grad.data_ptr(),
-                                     lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
-            d = dprev
-            continue
-        check(L.imx_mlp_dw(M, lin.out_features, lin.in_features, d.data_ptr(), d.stride(0), x.data_ptr(), x.stride(0),
-                           lin.weight.grad.data_ptr(), lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+        N, K = lin.out_features, lin.in_features
+        if pending is not None:
+            dh, h, alpha = pending
+            pending = None
+            d = torch.empty_like(dh) if i > 0 else None  # the input layer has nothing below it: dZ is not materialised
+            check(L.imx_mlp_dw_elu(M, N, K, dh.data_ptr(), dh.stride(0), h.data_ptr(), h.stride(0), float(alpha),
+                                   _lib.ptr(d), N, x.data_ptr(), x.stride(0), lin.weight.grad.data_ptr(),
+                                   lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+        else:
+            if not d.is_contiguous():
+                d = d.contiguous()
+            if i > 0 and _is_head(lin, x) and (prev_act is None or isinstance(prev_act, nn.ELU)):
+                dprev = torch.empty(M, K, device=d.device, dtype=d.dtype)
+                check(L.imx_mlp_head_bwd(M, K, N, d.data_ptr(), x.data_ptr(), x.stride(0), lin.weight.data_ptr(),
+                                         float(prev_act.alpha) if prev_act is not None else 0.0, int(prev_act is not None),
+                                         dprev.data_ptr(), lin.weight.grad.data_ptr(), lin.bias.grad.data_ptr(),
+                                         scratch.data_ptr(), scratch.numel(), stream))
+                d = dprev
+                continue
+            check(L.imx_mlp_dw(M, N, K, d.data_ptr(), d.stride(0), x.data_ptr(), x.stride(0), lin.weight.grad.data_ptr(),
+                               lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
         if i > 0:
             dx = torch.mm(d, lin.weight)
-            if isinstance(prev_act, nn.ELU):  # ELU'(z) from the saved output: y > 0 ? 1 : y + alpha
+            if isinstance(prev_act, nn.ELU) and dx.stride(1) == 1 and saved[i].stride(1) == 1:
+                pending = (dx, saved[i], prev_act.alpha)  # ELU'(z) from the saved output: y > 0 ? 1 : y + alpha
+            elif isinstance(prev_act, nn.ELU):
                 d = torch.ops.aten.elu_backward(dx, prev_act.alpha, 1.0, 1.0, True, saved[i])
             elif prev_act is None:
                 d = dx

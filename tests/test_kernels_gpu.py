@@ -203,6 +203,33 @@ def test_mlp_dw_matches_fp64(libimx, M, N, K):
     assert libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), None, scratch.data_ptr(), 16, st) != 0
 
 
+@pytest.mark.parametrize("M,N,K", [(24576, 512, 235), (4099, 128, 256), (333, 130, 37)])
+def test_mlp_dw_elu_fuses_the_activation_backward(libimx, M, N, K):
+    """imx_mlp_dw_elu == aten elu_backward followed by imx_mlp_dw, bit for bit (same arithmetic, same summation order)."""
+    from isaaclab_amd import _lib
+
+    g = torch.Generator().manual_seed(M + K)
+    dH = torch.randn(M, N, generator=g).cuda()
+    H = torch.nn.functional.elu(torch.randn(M, N, generator=g)).cuda()
+    X = torch.randn(M, K, generator=g).cuda()
+    nbytes = int(libimx.imx_mlp_scratch_bytes(M, N, K))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dZ_ref = torch.ops.aten.elu_backward(dH, 1.0, 1.0, 1.0, True, H)
+    dW0, db0 = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    _lib.check(libimx.imx_mlp_dw(M, N, K, dZ_ref.data_ptr(), N, X.data_ptr(), K, dW0.data_ptr(), db0.data_ptr(), scratch.data_ptr(), nbytes, st))
+    dW1, db1, dZ = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda"), torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(libimx.imx_mlp_dw_elu(M, N, K, dH.data_ptr(), N, H.data_ptr(), N, 1.0, dZ.data_ptr(), N, X.data_ptr(), K, dW1.data_ptr(),
+                                     db1.data_ptr(), scratch.data_ptr(), nbytes, st))
+    assert torch.equal(dZ, dZ_ref) and torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    # no layer below: dZ is not materialised
+    _lib.check(libimx.imx_mlp_dw_elu(M, N, K, dH.data_ptr(), N, H.data_ptr(), N, 1.0, None, 0, X.data_ptr(), K, dW1.data_ptr(),
+                                     db1.data_ptr(), scratch.data_ptr(), nbytes, st))
+    assert torch.equal(dW1, dW0)
+    assert libimx.imx_mlp_dw_elu(M, N, K, dH.data_ptr(), N, H.data_ptr(), N, 1.0, dH.data_ptr(), N, X.data_ptr(), K, dW1.data_ptr(),
+                                 db1.data_ptr(), scratch.data_ptr(), nbytes, st) != 0  # in-place is refused
+
+
 @pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5)])
 def test_mlp_head_matches_autograd(libimx, M, K, A):
     """imx_mlp_head_fwd / imx_mlp_head_bwd against torch (fp64) for the layer  y = ELU(z) W^T + b."""

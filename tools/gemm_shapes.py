@@ -47,6 +47,12 @@ for net, dims in (("actor", [235, 512, 256, 128, 12]), ("critic", [235, 512, 256
         st = torch.cuda.current_stream().cuda_stream
         t_imx = timeit(lambda: L.imx_mlp_dw(M, N, K, d.data_ptr(), N, x.data_ptr(), K, gW.data_ptr(), gb.data_ptr(), scr.data_ptr(), nb, st))
         extra = f" | imx_dw+db {t_imx:7.1f} us {fl / t_imx / 1e6:6.1f} TF"
+        hh = torch.nn.functional.elu(torch.randn(M, N, device=dev))
+        dz = torch.empty(M, N, device=dev)
+        t_elu = timeit(lambda: torch.ops.aten.elu_backward(d, 1.0, 1.0, 1.0, True, hh))
+        t_fused = timeit(lambda: L.imx_mlp_dw_elu(M, N, K, d.data_ptr(), N, hh.data_ptr(), N, 1.0, dz.data_ptr(), N, x.data_ptr(), K,
+                                                  gW.data_ptr(), gb.data_ptr(), scr.data_ptr(), nb, st))
+        extra += f" | elu_bwd {t_elu:5.1f} us, imx_dw_elu {t_fused:6.1f} us"
         if N <= 16:
             y = torch.empty(M, N, device=dev)
             dp = torch.empty(M, K, device=dev)
