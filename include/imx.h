@@ -361,6 +361,17 @@ int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_t ldg, cons
                    float* dZ_out_d, int64_t ldd, const float* X_d, int64_t ldx, float* dW_d, float* db_d, void* scratch_d,
                    size_t scratch_bytes, imx_stream_t stream);
 
+/* Rollout inference (rsl_rl actor_critic.py::act / evaluate): the whole Linear+ELU stack of up to two
+ * networks sharing the input X (M, dims[0]; pitch ldx) in ONE launch, 32 samples per workgroup, activations in LDS.
+ * nlayers[k] <= 4 Linear layers per network, ELU(elu_alpha[k]) after every layer but the last; dims = the layer widths of
+ * network 0 (nlayers[0]+1 values, each <= 512) followed by those of network 1; weights_d / biases_d = HOST arrays of device
+ * pointers, network 0's layers first; W (out,in) row-major with row pitch weight_pitch[i] floats (NULL = dense), which must
+ * be a multiple of 32 with ZERO padding and 16-byte aligned rows -- a 235-wide first layer is passed as a padded copy
+ * (pitch 256) -- so that every weight load is an unconditional 16-byte load; out_d[k] (M, last width). */
+int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
+                  const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
+                  float* const* out_d, imx_stream_t stream);
+
 /* Output layer forward, A <= 16 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K). */
 int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
                      imx_stream_t stream);

@@ -90,6 +90,8 @@ _SIGNATURES = {
     "imx_mlp_dw": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "imx_mlp_dw_elu": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "imx_mlp_infer": (c_int, [c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
     "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_mlp_head_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -521,3 +521,200 @@ extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, cons
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------- fused MLP inference (rollout)
+// PPO.act / evaluate during the rollout (upstream actor_critic.py::act_inference / evaluate): the whole
+// Linear+ELU stack of BOTH networks in one launch.  A workgroup owns 32 samples and carries them through every layer with
+// the activations in LDS (two ping-pong buffers); weights go global -> registers (every weight is used once per
+// workgroup, so LDS staging would buy nothing): per 32 reduction indices a lane loads one full 64-byte half of a weight
+// row (the two half-waves cover one 128-byte line per row) and the matching 4 x 16 bytes of activations from LDS, then
+// issues 16 MFMAs per 32-column block.  blockIdx selects the network: actor and critic fill all CUs together at
+// N = 4096 (2 x 128 workgroups), where per-layer library GEMMs on M = 4096 rows leave most of the chip idle.
+constexpr int INF_ROWS = 32, INF_MAXD = 512, INF_PITCH = INF_MAXD + 4, INF_MAXL = 4;
+
+struct InferNet {
+    const float* W[INF_MAXL];
+    const float* b[INF_MAXL];
+    int ldw[INF_MAXL];   // row pitch of W (floats): multiple of 32, zero padded
+    int dim[INF_MAXL + 1];
+    int nlayers;
+    float alpha;     // ELU alpha of the hidden layers
+    float* out;      // (M, dim[nlayers])
+};
+struct InferArgs {
+    int64_t M;
+    const float* X;
+    int64_t ldx;
+    int tiles;       // workgroups per network
+    InferNet net[2];
+    int nnets;
+};
+
+// One layer for the 32 samples of the workgroup.  NBW = 32-column output blocks per wave (4, 2 or 1); a reduction GROUP is
+// GS = 4 / NBW sub-groups of 32 indices, so that every group is 64 MFMAs per wave (4096 cycles, more than an L2 round trip)
+// whatever the layer width.  Two operand sets (P, Q) ping-pong: the loads of group g+1 are issued before the MFMAs of group
+// g.  Every load in the loop is UNCONDITIONAL (indices clamped; the host guarantees zero-padded weight rows with a pitch
+// that is a multiple of 32, activation columns beyond K are zero in LDS, column blocks beyond N re-read row N-1 and are
+// dropped in the epilogue): a load inside a divergent branch makes the compiler wait for all outstanding loads at the
+// join, which measured 2x slower here.
+template <int NBW>
+__device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K, const float* __restrict__ W, int ldw,
+                                            const float* __restrict__ bias, int N, bool elu, float alpha, float* __restrict__ sOut,
+                                            float* __restrict__ gOut, int64_t m0, int64_t M) {
+    constexpr int GS = 4 / NBW;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+    const int nsub = (K + 31) >> 5;            // 32-index sub-groups
+    const int ng = (nsub + GS - 1) / GS;       // groups
+    const float* wrow[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int n = (w + 4 * j) * 32 + r;
+        wrow[j] = W + (size_t)(n < N ? n : N - 1) * ldw + 16 * half;
+    }
+    const float* arow = sIn + r * INF_PITCH + 16 * half;
+    float4 Pa[GS][4], Qa[GS][4], Pb[NBW][GS][4], Qb[NBW][GS][4];
+    // sub-groups past the end (a group may be partial) are clamped to the last one for the loads and multiplied by zero
+    auto load = [&](float4 (&a)[GS][4], float4 (&b)[NBW][GS][4], int g) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const int sg = g * GS + u;
+            const int sc = sg < nsub ? sg : nsub - 1;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[j][u][i] = *reinterpret_cast<const float4*>(wrow[j] + 32 * sc + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = *reinterpret_cast<const float4*>(arow + 32 * sc + 4 * i);
+                if (sg >= nsub) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                a[u][i] = v;
+            }
+        }
+    };
+    auto mult = [&](const float4 (&a)[GS][4], const float4 (&b)[NBW][GS][4]) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GS; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i].x, b[j][u][i].x, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i].y, b[j][u][i].y, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i].z, b[j][u][i].z, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i].w, b[j][u][i].w, acc[j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load(Pa, Pb, 0);
+    int g = 0;
+    for (; g + 1 < ng; g += 2) {
+        load(Qa, Qb, g + 1);
+        mult(Pa, Pb);
+        load(Pa, Pb, g + 2 < ng ? g + 2 : ng - 1);  // clamped: at most one redundant reload at the end
+        mult(Qa, Qb);
+    }
+    if (g < ng) mult(Pa, Pb);  // odd number of groups: P holds the last one
+    // epilogue: accumulator rows = samples (registers), columns = out-features (lanes)
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int n = (w + 4 * j) * 32 + r;
+        if (n >= N) continue;
+        const float bv = bias[n];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = acc_row(q, half);
+            float v = acc[j][q] + bv;
+            if (elu) v = v > 0.0f ? v : (expf(v) - 1.0f) * alpha;
+            if (sOut) sOut[row * INF_PITCH + n] = v;
+            else if (m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
+    extern __shared__ float smem[];  // two activation buffers of INF_ROWS x INF_PITCH floats
+    float* buf0 = smem;
+    float* buf1 = smem + INF_ROWS * INF_PITCH;
+    const int which = blockIdx.x / a.tiles;
+    const InferNet& net = a.net[which];
+    const int64_t m0 = (int64_t)(blockIdx.x - which * a.tiles) * INF_ROWS;
+    // input rows -> LDS (the 32 rows are one contiguous run when ldx == dim[0]); columns up to the next multiple of 32 are zeroed
+    const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
+    for (int i = threadIdx.x; i < INF_ROWS * K0p; i += blockDim.x) {
+        const int row = i / K0p, col = i - row * K0p;
+        buf0[row * INF_PITCH + col] = (col < K0 && m0 + row < a.M) ? a.X[(m0 + row) * a.ldx + col] : 0.0f;
+    }
+    __syncthreads();
+    float* in = buf0;
+    float* out = buf1;
+    for (int l = 0; l < net.nlayers; ++l) {
+        const int K = net.dim[l], N = net.dim[l + 1];
+        const bool last = l == net.nlayers - 1;
+        const int nbw = ((N + 31) / 32 + 3) / 4;  // 32-column blocks per wave
+        float* so = last ? nullptr : out;
+        if (!last) {  // zero the padding columns the next layer's 32-wide reduction groups will read
+            const int Np = (N + 31) & ~31;
+            for (int i = threadIdx.x; i < INF_ROWS * (Np - N); i += blockDim.x) {
+                const int row = i / (Np - N), col = N + i - row * (Np - N);
+                out[row * INF_PITCH + col] = 0.0f;
+            }
+        }
+        if (nbw <= 1) infer_layer<1>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else if (nbw == 2) infer_layer<2>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else infer_layer<4>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        __syncthreads();
+        float* t = in; in = out; out = t;
+    }
+}
+
+extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
+                             const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
+                             float* const* out_d, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && X_d && nnets >= 1 && nnets <= 2 && nlayers && dims && weights_d && biases_d && elu_alpha && out_d,
+                "imx_mlp_infer: bad arguments");
+    InferArgs a;
+    a.M = M; a.X = X_d; a.ldx = ldx; a.nnets = nnets;
+    a.tiles = (int)((M + INF_ROWS - 1) / INF_ROWS);
+    int wi = 0, di = 0;
+    for (int k = 0; k < nnets; ++k) {
+        InferNet& n = a.net[k];
+        n.nlayers = nlayers[k];
+        IMX_REQUIRE(n.nlayers >= 1 && n.nlayers <= INF_MAXL, "imx_mlp_infer: network %d has %d layers (1..%d supported)", k, n.nlayers, INF_MAXL);
+        for (int l = 0; l <= n.nlayers; ++l) {
+            n.dim[l] = dims[di++];
+            IMX_REQUIRE(n.dim[l] >= 1 && n.dim[l] <= INF_MAXD, "imx_mlp_infer: layer width %d outside 1..%d", n.dim[l], INF_MAXD);
+        }
+        IMX_REQUIRE(n.dim[0] == a.net[0].dim[0] && ldx >= n.dim[0], "imx_mlp_infer: the networks must share the input (width %d, pitch %lld)",
+                    a.net[0].dim[0], (long long)ldx);
+        for (int l = 0; l < n.nlayers; ++l) {
+            n.W[l] = weights_d[wi];
+            n.b[l] = biases_d[wi];
+            n.ldw[l] = weight_pitch ? weight_pitch[wi] : n.dim[l];
+            ++wi;
+            IMX_REQUIRE(n.W[l] && n.b[l], "imx_mlp_infer: null weight / bias (network %d, layer %d)", k, l);
+            IMX_REQUIRE(n.ldw[l] >= n.dim[l] && n.ldw[l] % 32 == 0 && aligned16(n.W[l]),
+                        "imx_mlp_infer: weights of network %d layer %d need a 16-byte aligned, zero-padded row pitch that is a multiple "
+                        "of 32 floats (pitch %d, in-features %d)", k, l, n.ldw[l], n.dim[l]);
+        }
+        n.alpha = elu_alpha[k];
+        n.out = out_d[k];
+        IMX_REQUIRE(n.out, "imx_mlp_infer: null output (network %d)", k);
+    }
+    const size_t lds = 2ull * INF_ROWS * INF_PITCH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_infer, dim3((unsigned)(a.tiles * nnets)), dim3(256), lds, (hipStream_t)stream, a);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

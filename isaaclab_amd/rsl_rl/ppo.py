@@ -118,6 +118,72 @@ def _mlp_layers(seq: nn.Sequential):
     return out
 
 
+class FusedInference:
+    """``imx_mlp_infer`` bound to one or two Linear+ELU stacks (actor, critic) that share their input: argument arrays are
+    built once (the parameters live at fixed addresses in the flat bucket)."""
+
+    MAX_WIDTH, MAX_LAYERS = 512, 4
+
+    def __init__(self, *nets):
+        import ctypes
+
+        self.ok = 1 <= len(nets) <= 2
+        dims, ws, bs, alphas, nl = [], [], [], [], []
+        for layers in nets:
+            acts = [a for _, a in layers[:-1]]
+            if (len(layers) > self.MAX_LAYERS or layers[-1][1] is not None or any(not isinstance(a, nn.ELU) for a in acts)
+                    or any(max(lin.in_features, lin.out_features) > self.MAX_WIDTH for lin, _ in layers)
+                    or layers[0][0].in_features != nets[0][0][0].in_features):
+                self.ok = False
+                return
+            nl.append(len(layers))
+            dims += [layers[0][0].in_features] + [lin.out_features for lin, _ in layers]
+            ws += [lin.weight for lin, _ in layers]
+            bs += [lin.bias for lin, _ in layers]
+            alphas.append(float(acts[0].alpha) if acts else 1.0)
+        self.in_features = dims[0]
+        self.out_features = [layers[-1][0].out_features for layers in nets]
+        # Layers whose in-features are not a multiple of 32 (235 observations) get a zero-padded copy of their weights with a
+        # row pitch that is (the kernel issues unconditional 16-byte loads over whole 32-wide reduction groups);
+        # ``refresh()`` re-copies them after the parameters changed (once per rollout).
+        self._padded = []
+        pitch, wp = [], []
+        for w in ws:
+            k = w.shape[1]
+            if k % 32 == 0 and w.data_ptr() % 16 == 0:
+                pitch.append(k)
+                wp.append(w)
+            else:
+                kp = (k + 31) & ~31
+                buf = torch.zeros(w.shape[0], kp, device=w.device, dtype=w.dtype)
+                self._padded.append((buf, w))
+                pitch.append(kp)
+                wp.append(buf)
+        self._keep = (ws, bs, wp)
+        self._nl = (ctypes.c_int * len(nl))(*nl)
+        self._dims = (ctypes.c_int * len(dims))(*dims)
+        self._w = (ctypes.c_void_p * len(wp))(*[w.data_ptr() for w in wp])
+        self._pitch = (ctypes.c_int * len(pitch))(*pitch)
+        self._b = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
+        self._alpha = (ctypes.c_float * len(alphas))(*alphas)
+        self._n = len(nets)
+        self._ctypes = ctypes
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Re-copy the padded weight buffers from the live parameters (capturable: plain device copies)."""
+        for buf, w in self._padded:
+            buf[:, :w.shape[1]].copy_(w)
+
+    def __call__(self, x: torch.Tensor, *outs: torch.Tensor):
+        if x.stride(1) != 1 or x.shape[1] != self.in_features or any(not o.is_contiguous() for o in outs):
+            raise _lib.ImxError("imx_mlp_infer needs a row-major input and contiguous outputs")
+        out_p = (self._ctypes.c_void_p * self._n)(*[o.data_ptr() for o in outs])
+        check(lib().imx_mlp_infer(x.shape[0], x.data_ptr(), x.stride(0), self._n, self._nl, self._dims, self._w, self._pitch, self._b,
+                                  self._alpha, out_p, _lib.current_stream(x.device)))
+
+
 HEAD_MAX_OUT = 16  # imx_mlp_head_*: output layers up to 16 wide (action means, value)
 
 
@@ -251,6 +317,15 @@ class PPO:
         self._ws: dict = {}
         self._side = None
         self.two_streams = kwargs.get("two_streams", True)
+        if self.device.type == "cuda":
+            # HIP binds a stream to one of a few hardware queues at its FIRST use, round-robin: touch the update's streams
+            # now, in a fixed order, so that main / side / aux never end up sharing a queue depending on what ran before
+            # (measured: update 19.2 ms when the side stream was first used after the rollout graph, 18.3 ms otherwise)
+            for st in (self._side_stream(), self._aux_stream()):
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        torch.zeros(1, device=self.device)
+            torch.cuda.synchronize(self.device)
 
     @property
     def learning_rate(self) -> float:

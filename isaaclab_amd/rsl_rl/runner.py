@@ -132,19 +132,31 @@ class OnPolicyRunner:
         step_ptr = env._counters[2:3].data_ptr()
         bootstrap = 0 if env.is_finite_horizon else 1
         obs = self._obs
+        if self._infer is not None:
+            self._infer.refresh()  # the update changed the parameters: padded weight copies follow (inside the graph too)
         for t in range(self.num_steps_per_env):
-            side = alg._side_stream()
-            if side is not None:  # critic beside the actor (fork/join is capturable: both streams join the graph)
-                main = torch.cuda.current_stream(self.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    value, _ = mlp_forward(alg._critic_layers, obs)
-                mu, _ = mlp_forward(alg._actor_layers, obs)
-                main.wait_stream(side)
-                value.record_stream(main)
+            if self._infer is None:
+                from .ppo import FusedInference
+
+                self._infer = FusedInference(alg._actor_layers, alg._critic_layers)
+                self._mu_buf = torch.empty(N, A, device=self.device)
+                self._value_buf = torch.empty(N, 1, device=self.device)
+            if self._infer.ok:  # both networks, all layers, one launch (activations stay in LDS)
+                mu, value = self._mu_buf, self._value_buf
+                self._infer(obs, mu, value)
             else:
-                mu, _ = mlp_forward(alg._actor_layers, obs)
-                value, _ = mlp_forward(alg._critic_layers, obs)
+                side = alg._side_stream()
+                if side is not None:  # critic beside the actor (fork/join is capturable: both streams join the graph)
+                    main = torch.cuda.current_stream(self.device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        value, _ = mlp_forward(alg._critic_layers, obs)
+                    mu, _ = mlp_forward(alg._actor_layers, obs)
+                    main.wait_stream(side)
+                    value.record_stream(main)
+                else:
+                    mu, _ = mlp_forward(alg._actor_layers, obs)
+                    value, _ = mlp_forward(alg._critic_layers, obs)
             check(L.imx_policy_act(N, A, D, mu.data_ptr(), pol.std.data_ptr(), value.data_ptr(), obs.data_ptr(),
                                    self._act_seed, step_ptr, st.actions[t].data_ptr(), st.actions_log_prob[t].data_ptr(),
                                    st.mu[t].data_ptr(), st.sigma[t].data_ptr(), st.values[t].data_ptr(),
@@ -161,6 +173,7 @@ class OnPolicyRunner:
         return obs
 
     _graph_capturing = False
+    _infer = None
 
     def collect(self):
         """One rollout of ``num_steps_per_env`` env steps into the storage (eager, or one hipGraph replay)."""

@@ -230,6 +230,36 @@ def test_mlp_dw_elu_fuses_the_activation_backward(libimx, M, N, K):
                                  db1.data_ptr(), scratch.data_ptr(), nbytes, st) != 0  # in-place is refused
 
 
+@pytest.mark.parametrize("M,D,hidden,A", [(4096, 235, (512, 256, 128), 12), (100, 48, (128, 128, 128), 12), (33, 310, (512, 256, 128), 37),
+                                          (5, 4, (32,), 1), (70, 37, (64, 32), 5)])
+def test_mlp_infer_matches_torch(libimx, M, D, hidden, A):
+    """imx_mlp_infer (both networks, all layers, one launch) against the nn.Sequential stacks in fp64."""
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import FusedInference, _mlp_layers
+
+    torch.manual_seed(M + D)
+    pol = ActorCritic(D, D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=1.0).cuda()
+    for p in pol.parameters():  # biases are zero-initialised: make them count
+        if p.dim() == 1:
+            p.data.normal_(0.0, 0.3)
+    x = torch.randn(M, D, device="cuda")
+    inf = FusedInference(_mlp_layers(pol.actor), _mlp_layers(pol.critic))
+    assert inf.ok
+    mu, val = torch.full((M, A), float("nan"), device="cuda"), torch.full((M, 1), float("nan"), device="cuda")
+    inf(x, mu, val)
+    with torch.no_grad():  # parameters change -> refresh() updates the padded copies
+        for p in pol.parameters():
+            p.mul_(1.5)
+    inf.refresh()
+    inf(x, mu, val)
+    ref_mu = pol.actor.double()(x.double())
+    ref_v = pol.critic.double()(x.double())
+    assert float((mu.double() - ref_mu).abs().max()) <= 1e-5 * max(1.0, float(ref_mu.abs().max()))
+    assert float((val.double() - ref_v).abs().max()) <= 1e-5 * max(1.0, float(ref_v.abs().max()))
+    wide = ActorCritic(D, D, A, actor_hidden_dims=[1024], critic_hidden_dims=[1024]).cuda()
+    assert not FusedInference(_mlp_layers(wide.actor), _mlp_layers(wide.critic)).ok  # wider than 512: the library path is used
+
+
 @pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5)])
 def test_mlp_head_matches_autograd(libimx, M, K, A):
     """imx_mlp_head_fwd / imx_mlp_head_bwd against torch (fp64) for the layer  y = ELU(z) W^T + b."""
