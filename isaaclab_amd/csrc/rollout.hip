@@ -187,16 +187,22 @@ k_ppo_fwd(int64_t M, int A, const float* __restrict__ mu, const float* __restric
 // surrogate, entropy, kl, 1} (the running means rsl_rl logs per update)
 __global__ void k_ppo_finish(int nblk, float inv_m, float vcoef, float ecoef, const float* __restrict__ part,
                              float* __restrict__ out8, float* __restrict__ accum) {
+    // 64 lanes: lane = (chunk of blocks, quantity); chunks combined in a fixed order (deterministic)
+    __shared__ float red[16][4];
     __shared__ float r[4];
-    const int q = threadIdx.x;
-    if (q < 4) {
-        float s = 0.0f;
-        for (int b = 0; b < nblk; ++b) s += part[4 * b + q];
-        r[q] = s * inv_m;
-        out8[q] = r[q];
+    const int q = threadIdx.x & 3, chunk = threadIdx.x >> 2;
+    float s = 0.0f;
+    for (int b = chunk; b < nblk; b += 16) s += part[4 * b + q];
+    red[chunk][q] = s;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float tot = 0.0f;
+        for (int c = 0; c < 16; ++c) tot += red[c][threadIdx.x];
+        r[threadIdx.x] = tot * inv_m;
+        out8[threadIdx.x] = r[threadIdx.x];
     }
     __syncthreads();
-    if (q == 0) {
+    if (threadIdx.x == 0) {
         out8[4] = r[0] + vcoef * r[1] - ecoef * r[2];
         if (accum) {
             accum[0] += r[1]; accum[1] += r[0]; accum[2] += r[2]; accum[3] += r[3]; accum[4] += 1.0f;
@@ -383,9 +389,19 @@ k_adam_norm_prepare(int64_t n, const float* __restrict__ g, float* __restrict__ 
         if (last) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    float tot = 0.0f;
-    for (int b = 0; b < G; ++b) tot += __builtin_nontemporal_load(scratch + b);
+    if (!last) return;
+    // last block: all lanes fetch partials in parallel (a single lane walking them pays one uncached round trip each),
+    // then the same fixed-order tree as above
+    float part = 0.0f;
+    for (int b = threadIdx.x; b < G; b += ADAM_NORM_BLOCK) part += __builtin_nontemporal_load(scratch + b);
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int w = ADAM_NORM_BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float tot = red[0];
     *ticket = 0u;
     const float norm = sqrtf(tot);
     float lr = st[0];
