@@ -648,9 +648,34 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
     const int64_t m0 = (int64_t)(blockIdx.x - which * a.tiles) * INF_ROWS;
     // input rows -> LDS (the 32 rows are one contiguous run when ldx == dim[0]); columns up to the next multiple of 32 are zeroed
     const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
-    for (int i = threadIdx.x; i < INF_ROWS * K0p; i += blockDim.x) {
-        const int row = i / K0p, col = i - row * K0p;
-        buf0[row * INF_PITCH + col] = (col < K0 && m0 + row < a.M) ? a.X[(m0 + row) * a.ldx + col] : 0.0f;
+    {
+        // wave w takes rows w, w+4, ...; lanes run along the row.  All loads of a half tile are issued before the first LDS
+        // store (a load -> store loop pays one HBM round trip per iteration: 16 us for 235 columns).
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int hrow = 0; hrow < 2; ++hrow) {
+            float v[4][INF_MAXD / 64];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = w + 4 * (rr + 4 * hrow);
+                const float* src = a.X + (m0 + row < a.M ? m0 + row : 0) * a.ldx;
+#pragma unroll
+                for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                    const int c = lane + 64 * cc;
+                    const float x = src[c < K0 ? c : 0];  // clamped, unconditional
+                    v[rr][cc] = (c < K0 && m0 + row < a.M) ? x : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = w + 4 * (rr + 4 * hrow);
+#pragma unroll
+                for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                    const int c = lane + 64 * cc;
+                    if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
+                }
+            }
+        }
     }
     __syncthreads();
     float* in = buf0;
