@@ -353,6 +353,16 @@ size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_features);
 int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* X_d, int64_t ldx, float* dW_d,
                float* db_d, void* scratch_d, size_t scratch_bytes, imx_stream_t stream);
 
+/* Deferred reductions: imx_mlp_dw / imx_mlp_dw_elu / imx_mlp_head_bwd end with a small kernel that sums their split partials
+ * into dW / db.  Between imx_reduce_batch_begin(b) and imx_reduce_batch_flush(b, stream), calls issued from the SAME host
+ * thread queue that step on `b` instead (at most 8) and flush launches one kernel for all of them: dW / db are only needed
+ * by the optimiser, so the backward chain loses a 6 us launch per layer.  Every deferred call needs its OWN scratch. */
+typedef struct imx_reduce_batch imx_reduce_batch_t;
+int imx_reduce_batch_create(imx_reduce_batch_t** out);
+void imx_reduce_batch_destroy(imx_reduce_batch_t* batch);
+int imx_reduce_batch_begin(imx_reduce_batch_t* batch);
+int imx_reduce_batch_flush(imx_reduce_batch_t* batch, imx_stream_t stream);
+
 /* Same with the ELU backward of this layer fused in: dH_d is the gradient w.r.t. the layer's ACTIVATED output h = ELU(z),
  * H_d that saved output; dZ = dH * (h > 0 ? 1 : h + elu_alpha) (aten elu_backward with is_result) is formed on the way
  * into LDS -- no separate elementwise pass -- and written to dZ_out_d (M,N; may be NULL when no layer below needs it; must

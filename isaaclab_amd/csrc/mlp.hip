@@ -284,6 +284,52 @@ __global__ void __launch_bounds__(64 * RED_Y) k_mlp_reduce(int64_t total, int S,
     }
 }
 
+// Several partial reductions in ONE launch (deferred mode, see imx_reduce_batch_*): the weight / bias gradients are only
+// needed by the optimiser step, so the per-layer k_mlp_reduce launches -- 6-7 us each, sitting between the big kernels of
+// the backward chain -- are collected on the host and flushed together.
+constexpr int RED_MAX_SEG = 8;
+struct ReduceSeg {
+    int64_t total;
+    const float* part;
+    float* out;
+    const float* part_db;
+    float* db;
+    int S, N;
+    unsigned first_block;
+};
+struct ReduceBatchArgs {
+    ReduceSeg seg[RED_MAX_SEG];
+    int n;
+};
+__global__ void __launch_bounds__(64 * RED_Y) k_mlp_reduce_batch(ReduceBatchArgs a) {
+    __shared__ float red[RED_Y][64];
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < RED_MAX_SEG; ++q) k += (q < a.n && blockIdx.x >= a.seg[q].first_block) ? 1 : 0;
+    const ReduceSeg& g = a.seg[k];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int64_t i = (int64_t)(blockIdx.x - g.first_block) * 64 + tx;
+    const float* src = nullptr;
+    int64_t stride = 0;
+    float* dst = nullptr;
+    if (i < g.total) {
+        src = g.part + i; stride = g.total; dst = g.out + i;
+    } else if (g.db && i - g.total < g.N) {
+        src = g.part_db + (i - g.total); stride = g.N; dst = g.db + (i - g.total);
+    }
+    float acc = 0.0f;
+    if (src)
+        for (int s = ty; s < g.S; s += RED_Y) acc += src[(size_t)s * stride];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && dst) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int y = 0; y < RED_Y; ++y) sum += red[y][tx];
+        *dst = sum;
+    }
+}
+
 struct DwPlan {
     int tn, tk, S;
     int64_t rps;
@@ -431,6 +477,35 @@ extern "C" size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_feat
     return std::max(dw, head) + 256;
 }
 
+typedef struct imx_reduce_batch imx_reduce_batch_t;
+struct imx_reduce_batch {
+    ReduceBatchArgs args;
+    unsigned blocks;
+};
+static thread_local imx_reduce_batch* t_batch = nullptr;  // bound by imx_reduce_batch_begin on the issuing host thread
+
+namespace {
+
+// launch the reduction now, or queue it on the batch bound to this thread
+int reduce_or_defer(const char* who, int64_t total, int S, const float* part, float* out, int N, const float* part_db, float* db,
+                    hipStream_t st) {
+    const int64_t threads = total + (db ? N : 0);
+    const unsigned blocks = (unsigned)((threads + 63) / 64);
+    if (t_batch) {
+        IMX_REQUIRE(t_batch->args.n < RED_MAX_SEG, "%s: more than %d deferred reductions in one batch", who, RED_MAX_SEG);
+        ReduceSeg& g = t_batch->args.seg[t_batch->args.n++];
+        g.total = total; g.part = part; g.out = out; g.part_db = part_db; g.db = db; g.S = S; g.N = N;
+        g.first_block = t_batch->blocks;
+        t_batch->blocks += blocks;
+        return 0;
+    }
+    hipLaunchKernelGGL(k_mlp_reduce, dim3(blocks), dim3(64, RED_Y), 0, st, total, S, part, out, N, part_db, db);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
 static int mlp_dw_launch(const char* who, int64_t M, int N, int K, const float* dY_d, int64_t ldy, const float* H_d, int64_t ldh,
                          float alpha, float* Dout_d, int64_t ldd, const float* X_d, int64_t ldx, float* dW_d, float* db_d,
                          void* scratch_d, size_t scratch_bytes, imx_stream_t stream) {
@@ -469,8 +544,36 @@ static int mlp_dw_launch(const char* who, int64_t M, int N, int K, const float* 
     }
 #undef IMX_DW_LAUNCH
     IMX_HIP(hipGetLastError());
-    const int64_t total = (int64_t)N * K, threads = total + (db_d ? N : 0);
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((threads + 63) / 64)), dim3(64, RED_Y), 0, st, total, p.S, a.part, dW_d, N, a.part_db, db_d);
+    return reduce_or_defer(who, (int64_t)N * K, p.S, a.part, dW_d, N, a.part_db, db_d, st);
+}
+
+extern "C" int imx_reduce_batch_create(imx_reduce_batch_t** out) {
+    IMX_REQUIRE(out, "imx_reduce_batch_create: null argument");
+    *out = new imx_reduce_batch();
+    (*out)->args.n = 0;
+    (*out)->blocks = 0;
+    return 0;
+}
+
+extern "C" void imx_reduce_batch_destroy(imx_reduce_batch_t* b) {
+    if (t_batch == b) t_batch = nullptr;
+    delete b;
+}
+
+extern "C" int imx_reduce_batch_begin(imx_reduce_batch_t* b) {
+    IMX_REQUIRE(b, "imx_reduce_batch_begin: null batch");
+    IMX_REQUIRE(t_batch == nullptr, "imx_reduce_batch_begin: another batch is still open on this thread (flush it first)");
+    b->args.n = 0;
+    b->blocks = 0;
+    t_batch = b;
+    return 0;
+}
+
+extern "C" int imx_reduce_batch_flush(imx_reduce_batch_t* b, imx_stream_t stream) {
+    IMX_REQUIRE(b && t_batch == b, "imx_reduce_batch_flush: this batch is not the one open on this thread");
+    t_batch = nullptr;
+    if (b->args.n == 0) return 0;
+    hipLaunchKernelGGL(k_mlp_reduce_batch, dim3(b->blocks), dim3(64, RED_Y), 0, (hipStream_t)stream, b->args);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -516,10 +619,7 @@ extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, cons
     hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)G), dim3((unsigned)(K / 32 * 64)), 0, st, M, K, A, dY_d, h_d, ldh, W_d, elu_alpha,
                        has_activation, dprev_d, part, part_db);
     IMX_HIP(hipGetLastError());
-    const int64_t total = (int64_t)A * K, threads = total + A;
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((threads + 63) / 64)), dim3(64, RED_Y), 0, st, total, G, part, dW_d, A, part_db, db_d);
-    IMX_HIP(hipGetLastError());
-    return 0;
+    return reduce_or_defer("imx_mlp_head_bwd", (int64_t)A * K, G, part, dW_d, A, part_db, db_d, st);
 }
 
 // ------------------------------------------------------------------------------------------- fused MLP inference (rollout)

@@ -198,6 +198,27 @@ def mlp_scratch(layers, M: int, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+class DeferredReductions:
+    """Per-layer scratch + an ``imx_reduce_batch``: the split-partial sums of every layer of one network are flushed in ONE
+    launch at the end of ``mlp_backward`` (dW / db are only read by the optimiser step)."""
+
+    def __init__(self, layers, M: int, device):
+        import ctypes
+
+        L = lib()
+        self.scratch = [torch.empty(int(L.imx_mlp_scratch_bytes(M, lin.out_features, lin.in_features)), dtype=torch.uint8, device=device)
+                        for lin, _ in layers]
+        h = ctypes.c_void_p()
+        check(L.imx_reduce_batch_create(ctypes.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            lib().imx_reduce_batch_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def mlp_forward(layers, x, out=None):
     """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
     the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given)."""
@@ -237,6 +258,17 @@ def mlp_backward(layers, saved, dout, scratch=None):
     if scratch is None:
         scratch = mlp_scratch(layers, M, dout.device)
     stream = _lib.current_stream(dout.device)
+    deferred = scratch if isinstance(scratch, DeferredReductions) else None
+    if deferred is not None:
+        check(L.imx_reduce_batch_begin(deferred.handle))
+    try:
+        _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream)
+    finally:
+        if deferred is not None:
+            check(L.imx_reduce_batch_flush(deferred.handle, stream))
+
+
+def _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream):
     d = dout          # gradient w.r.t. the pre-activation output of layer i ...
     pending = None    # ... or (gradient w.r.t. its ELU output, that output, alpha): resolved inside imx_mlp_dw_elu
     for i in range(len(layers) - 1, -1, -1):
@@ -244,13 +276,14 @@ def mlp_backward(layers, saved, dout, scratch=None):
         x = saved[i] if not isinstance(saved[i], tuple) else saved[i][1]
         prev_act = layers[i - 1][1] if i > 0 else None
         N, K = lin.out_features, lin.in_features
+        scr = deferred.scratch[i] if deferred is not None else scratch
         if pending is not None:
             dh, h, alpha = pending
             pending = None
             d = torch.empty_like(dh) if i > 0 else None  # the input layer has nothing below it: dZ is not materialised
             check(L.imx_mlp_dw_elu(M, N, K, dh.data_ptr(), dh.stride(0), h.data_ptr(), h.stride(0), float(alpha),
                                    _lib.ptr(d), N, x.data_ptr(), x.stride(0), lin.weight.grad.data_ptr(),
-                                   lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+                                   lin.bias.grad.data_ptr(), scr.data_ptr(), scr.numel(), stream))
         else:
             if not d.is_contiguous():
                 d = d.contiguous()
@@ -259,11 +292,11 @@ def mlp_backward(layers, saved, dout, scratch=None):
                 check(L.imx_mlp_head_bwd(M, K, N, d.data_ptr(), x.data_ptr(), x.stride(0), lin.weight.data_ptr(),
                                          float(prev_act.alpha) if prev_act is not None else 0.0, int(prev_act is not None),
                                          dprev.data_ptr(), lin.weight.grad.data_ptr(), lin.bias.grad.data_ptr(),
-                                         scratch.data_ptr(), scratch.numel(), stream))
+                                         scr.data_ptr(), scr.numel(), stream))
                 d = dprev
                 continue
             check(L.imx_mlp_dw(M, N, K, d.data_ptr(), d.stride(0), x.data_ptr(), x.stride(0), lin.weight.grad.data_ptr(),
-                               lin.bias.grad.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+                               lin.bias.grad.data_ptr(), scr.data_ptr(), scr.numel(), stream))
         if i > 0:
             dx = torch.mm(d, lin.weight)
             if isinstance(prev_act, nn.ELU) and dx.stride(1) == 1 and saved[i].stride(1) == 1:
@@ -389,7 +422,7 @@ class PPO:
             dev = self.device
             ws = dict(dmu=torch.empty(M, A, device=dev), dsigma=torch.empty(M, A, device=dev), dvalue=torch.empty(M, 1, device=dev),
                       scratch=torch.empty(int(lib().imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device=dev),
-                      mlp_a=mlp_scratch(self._actor_layers, M, dev), mlp_c=mlp_scratch(self._critic_layers, M, dev))
+                      mlp_a=DeferredReductions(self._actor_layers, M, dev), mlp_c=DeferredReductions(self._critic_layers, M, dev))
             self._ws[(M, A)] = ws
         return ws
 

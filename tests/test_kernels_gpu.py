@@ -260,6 +260,41 @@ def test_mlp_infer_matches_torch(libimx, M, D, hidden, A):
     assert not FusedInference(_mlp_layers(wide.actor), _mlp_layers(wide.critic)).ok  # wider than 512: the library path is used
 
 
+def test_deferred_reductions_match_immediate(libimx):
+    """imx_reduce_batch_*: the partial sums of several layers flushed in one launch == the per-call reductions, bit for bit."""
+    from isaaclab_amd import _lib
+
+    M = 3000
+    shapes = [(256, 512), (128, 256), (12, 128)]
+    g = torch.Generator().manual_seed(4)
+    st = torch.cuda.current_stream().cuda_stream
+    data, ref = [], []
+    for N, K in shapes:
+        dY, X = torch.randn(M, N, generator=g).cuda(), torch.randn(M, K, generator=g).cuda()
+        nb = int(libimx.imx_mlp_scratch_bytes(M, N, K))
+        scr = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dW, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+        _lib.check(libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st))
+        ref.append((dW.clone(), db.clone()))
+        data.append((N, K, dY, X, scr, nb))
+    h = ctypes.c_void_p()
+    _lib.check(libimx.imx_reduce_batch_create(ctypes.byref(h)))
+    _lib.check(libimx.imx_reduce_batch_begin(h))
+    assert libimx.imx_reduce_batch_begin(h) != 0  # already open on this thread
+    outs = []
+    for N, K, dY, X, scr, nb in data:
+        dW, db = torch.full((N, K), float("nan"), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+        _lib.check(libimx.imx_mlp_dw(M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st))
+        outs.append((dW, db))
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(dW).all()) for dW, _ in outs)  # nothing reduced yet
+    _lib.check(libimx.imx_reduce_batch_flush(h, st))
+    for (dW, db), (rW, rb) in zip(outs, ref):
+        assert torch.equal(dW, rW) and torch.equal(db, rb)
+    assert libimx.imx_reduce_batch_flush(h, st) != 0  # not open any more
+    libimx.imx_reduce_batch_destroy(h)
+
+
 @pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5)])
 def test_mlp_head_matches_autograd(libimx, M, K, A):
     """imx_mlp_head_fwd / imx_mlp_head_bwd against torch (fp64) for the layer  y = ELU(z) W^T + b."""
