@@ -96,7 +96,7 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "imx_mlp_infer": (c_int, [c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
-    "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "imx_mlp_head_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
 }

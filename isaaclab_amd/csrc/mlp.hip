@@ -360,8 +360,12 @@ DwPlan dw_plan(int64_t M, int N, int K) {
 // ------------------------------------------------------------------------------------------------------------- head
 constexpr int HEAD_A = 16;  // widest output layer handled (actions / value)
 
-__global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, const float* __restrict__ h, int64_t ldh,
-                                                  const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y) {
+// ELU_IN: h holds the PRE-activation output of the layer below; ELU is applied on the way in and written back in place
+// (every element is read by exactly one lane), which saves that layer's separate activation pass.
+template <bool ELU_IN>
+__global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float* __restrict__ h, int64_t ldh,
+                                                  const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y,
+                                                  float alpha) {
     extern __shared__ float sW[];  // [A][K]
     for (int i = threadIdx.x; i < A * K; i += blockDim.x) sW[i] = W[i];
     __syncthreads();
@@ -371,9 +375,16 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, const
     float acc[HEAD_A];
 #pragma unroll
     for (int o = 0; o < HEAD_A; ++o) acc[o] = 0.0f;
-    const float* hr = h + (live ? row : 0) * ldh;
+    float* hr = h + (live ? row : 0) * ldh;
     for (int k = 4 * q; k < K; k += 16) {  // the 4 lanes of a sample read one 64-byte run per trip
-        const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+        float4 hv = *reinterpret_cast<const float4*>(hr + k);
+        if (ELU_IN) {
+            hv.x = hv.x > 0.0f ? hv.x : (expf(hv.x) - 1.0f) * alpha;
+            hv.y = hv.y > 0.0f ? hv.y : (expf(hv.y) - 1.0f) * alpha;
+            hv.z = hv.z > 0.0f ? hv.z : (expf(hv.z) - 1.0f) * alpha;
+            hv.w = hv.w > 0.0f ? hv.w : (expf(hv.w) - 1.0f) * alpha;
+            if (live) *reinterpret_cast<float4*>(hr + k) = hv;
+        }
 #pragma unroll
         for (int o = 0; o < HEAD_A; ++o)
             if (o < A) {
@@ -592,14 +603,18 @@ extern "C" int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_
                          scratch_bytes, stream);
 }
 
-extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, const float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
-                                imx_stream_t stream) {
+extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                                int elu_in_place, float elu_alpha, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && h_d && W_d && b_d && y_d, "imx_mlp_head_fwd: bad arguments");
     IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_fwd: %d outputs (1..%d supported; wider layers are library GEMMs)", A, HEAD_A);
     IMX_REQUIRE(K >= 16 && K % 16 == 0 && K <= 2048 && ldh >= K && ldh % 4 == 0 && aligned16(h_d),
                 "imx_mlp_head_fwd: in-features %d (pitch %lld) must be a multiple of 16, 16-byte aligned rows", K, (long long)ldh);
-    hipLaunchKernelGGL(k_head_fwd, dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M, K, A,
-                       h_d, ldh, W_d, b_d, y_d);
+    if (elu_in_place)
+        hipLaunchKernelGGL((k_head_fwd<true>), dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M,
+                           K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha);
+    else
+        hipLaunchKernelGGL((k_head_fwd<false>), dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M,
+                           K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha);
     IMX_HIP(hipGetLastError());
     return 0;
 }

@@ -224,6 +224,7 @@ def mlp_forward(layers, x, out=None):
     the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given)."""
     saved = [x]
     h = x
+    pending_elu = None  # ELU of the last hidden layer is applied by the head kernel on its way in (in place)
     for li, (lin, act) in enumerate(layers):
         if act is None and _is_head(lin, h):
             if out is not None and li == len(layers) - 1:
@@ -231,17 +232,29 @@ def mlp_forward(layers, x, out=None):
             else:
                 z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
             check(lib().imx_mlp_head_fwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
-                                         lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), _lib.current_stream(h.device)))
+                                         lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None),
+                                         float(pending_elu or 0.0), _lib.current_stream(h.device)))
+            pending_elu = None
         else:
+            if pending_elu is not None:
+                h = F.elu(h, alpha=pending_elu, inplace=True)
+                pending_elu = None
             z = torch.addmm(lin.bias, h, lin.weight.t())  # GEMM + bias epilogue (hipBLASLt)
         if act is None:
             h = z
         elif isinstance(act, nn.ELU):
-            h = F.elu(z, alpha=act.alpha, inplace=True)
+            nxt = layers[li + 1][0] if li + 1 < len(layers) else None
+            if nxt is not None and layers[li + 1][1] is None and _is_head(nxt, z) and li + 1 == len(layers) - 1:
+                pending_elu = float(act.alpha)  # z becomes ELU(z) inside the head kernel, same storage
+                h = z
+            else:
+                h = F.elu(z, alpha=act.alpha, inplace=True)
             saved.append(h)
         else:
             h = act(z)
             saved.append((z, h))
+    if pending_elu is not None:
+        h = F.elu(h, alpha=pending_elu, inplace=True)
     if out is not None and h is not out:
         out.copy_(h)
         h = out

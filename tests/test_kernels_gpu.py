@@ -170,7 +170,12 @@ def test_explicit_backward_matches_autograd(libimx):
     ref = alg.bucket.grad[:n]
     err = (got[:n] - ref).abs().max() / ref.abs().max()
     assert float(err) < 1e-5, f"flat gradient bucket: max err / max |g| = {float(err):.2e}"  # fp32 GEMM summation order
-    assert_close(got[:n], ref, 1e-5, "flat gradient bucket")
+    off = 0  # per parameter tensor: error relative to that tensor's largest gradient (summation-order noise scales with the
+    for name, p in pol.named_parameters():  # sum of |terms|, not with each element's own magnitude)
+        k = p.numel()
+        e_p = float((got[off:off + k] - ref[off:off + k]).abs().max())
+        assert e_p <= 1e-5 * max(float(ref[off:off + k].abs().max()), 1e-6), f"{name}: max err {e_p:.2e}"
+        off += k
     assert abs(float(got[n + 3]) - float(kl)) < 1e-6  # the loss scalars (KL = slot 3) ride behind the gradients
 
 
@@ -314,8 +319,14 @@ def test_mlp_head_matches_autograd(libimx, M, K, A):
     h = hd.detach().float()
     st = torch.cuda.current_stream().cuda_stream
     y = torch.empty(M, A, device="cuda")
-    _lib.check(libimx.imx_mlp_head_fwd(M, K, A, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st))
+    _lib.check(libimx.imx_mlp_head_fwd(M, K, A, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st))
     assert float((y.double() - yd.detach()).abs().max()) <= 1e-5
+    # ELU of the layer below applied on the way in, in place: z -> h (bit-identical to aten elu), same y
+    zz = z.clone()
+    y2 = torch.empty_like(y)
+    _lib.check(libimx.imx_mlp_head_fwd(M, K, A, zz.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), 1, alpha, st))
+    assert float((zz - torch.nn.functional.elu(z, alpha)).abs().max()) <= 1e-6
+    assert float((y2.double() - yd.detach()).abs().max()) <= 1e-5
     nbytes = int(libimx.imx_mlp_scratch_bytes(M, A, K))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     dprev, dW, db = torch.empty(M, K, device="cuda"), torch.empty(A, K, device="cuda"), torch.empty(A, device="cuda")
@@ -328,7 +339,7 @@ def test_mlp_head_matches_autograd(libimx, M, K, A):
     _lib.check(libimx.imx_mlp_head_bwd(M, K, A, dY.data_ptr(), h.data_ptr(), K, W.data_ptr(), 0.0, 0, dprev.data_ptr(), dW.data_ptr(),
                                        db.data_ptr(), scratch.data_ptr(), nbytes, st))
     assert float((dprev.double() - dY.double() @ W.double()).abs().max()) <= 1e-5
-    assert libimx.imx_mlp_head_fwd(M, K, 17, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st) != 0
+    assert libimx.imx_mlp_head_fwd(M, K, 17, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st) != 0
 
 
 @pytest.mark.parametrize("fused_norm", [False, True])

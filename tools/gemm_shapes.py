@@ -56,7 +56,7 @@ for net, dims in (("actor", [235, 512, 256, 128, 12]), ("critic", [235, 512, 256
         if N <= 16:
             y = torch.empty(M, N, device=dev)
             dp = torch.empty(M, K, device=dev)
-            t_hf = timeit(lambda: L.imx_mlp_head_fwd(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), st))
+            t_hf = timeit(lambda: L.imx_mlp_head_fwd(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st))
             t_hb = timeit(lambda: L.imx_mlp_head_bwd(M, K, N, d.data_ptr(), x.data_ptr(), K, W.data_ptr(), 1.0, 1, dp.data_ptr(), gW.data_ptr(),
                                                      gb.data_ptr(), scr.data_ptr(), nb, st))
             extra += f" | head fwd {t_hf:6.1f} us, head bwd (dW,db,dX,ELU') {t_hb:6.1f} us"
