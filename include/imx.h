@@ -204,7 +204,10 @@ int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx
 /* ObservationManager.compute (managers/observation_manager.py:238-335) fused with RayCaster._update_buffers_impl
  * (sensors/ray_caster/ray_caster.py:220-260) + raycast_mesh (utils/warp/ops.py:24-127).
  * noise_u_d: optional (N,D) uniform [0,1) samples replacing torch.rand_like (parity mode); NULL -> in-kernel
- * counter-based RNG keyed by (seed, step counter, env, column).  ray_hits_out_d: optional (N,R,3). */
+ * counter-based RNG keyed by (seed, step counter, env, column).  ray_hits_out_d: optional (N,R,3).
+ * Terms with ObservationTermCfg.history_length > 0 keep their flattened (H, d) window (oldest first; CircularBuffer,
+ * utils/buffers/circular_buffer.py:107-135) in the obs row itself: envs flagged in buf->reset_buf -- or every env when bit 1
+ * of enable_corruption is set (env.reset()) -- take the new value in every slot, the others slide by one. */
 int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
                      const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
                      float* ray_hits_out_d, imx_stream_t stream);

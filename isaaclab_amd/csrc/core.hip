@@ -121,8 +121,13 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
         const int op = r[IMX_R_OP];
         IMX_REQUIRE(op >= IMX_O_BASE_POS_Z && op <= IMX_O_EXTERNAL, "plan: unknown observation op %d", op);
         const int o = r[IMX_R_OUT], d = r[IMX_R_DIM];
-        IMX_REQUIRE(o >= 0 && d > 0 && o + d <= p->D, "plan: observation record %d columns [%d,%d) outside D=%d", k, o,
-                    o + d, p->D);
+        // history (ObservationTermCfg.history_length, AUX1): the record owns hist*d columns, oldest slot first; only the newest
+        // slot is computed, the older ones are shifted inside the obs buffer by the kernel
+        const int hist = op == IMX_O_EXTERNAL ? 1 : (r[IMX_R_AUX1] > 1 ? r[IMX_R_AUX1] : 1);
+        IMX_REQUIRE(op == IMX_O_EXTERNAL || (r[IMX_R_AUX1] >= 0 && r[IMX_R_AUX1] <= 64), "plan: observation record %d history length %d", k,
+                    r[IMX_R_AUX1]);
+        IMX_REQUIRE(o >= 0 && d > 0 && o + hist * d <= p->D, "plan: observation record %d columns [%d,%d) outside D=%d", k, o,
+                    o + hist * d, p->D);
         const bool joint = op == IMX_O_JOINT_POS || op == IMX_O_JOINT_POS_REL || op == IMX_O_JOINT_VEL ||
                            op == IMX_O_JOINT_VEL_REL || op == IMX_O_JOINT_POS_LIMIT_NORMALIZED;
         if (joint) {
@@ -139,12 +144,14 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
             IMX_REQUIRE(r[IMX_R_AUX0] >= 0 && r[IMX_R_AUX0] + d <= w[IMX_H_NEXT_OBS], "plan: ext_obs columns out of range");
         static const int fixed_dim[] = {0, 1, 3, 3, 3, 3, 4, 3, 3};
         if (op <= IMX_O_ROOT_ANG_VEL_W) IMX_REQUIRE(d == fixed_dim[op], "plan: observation op %d must have dim %d", op, fixed_dim[op]);
-        for (int j = 0; j < d; ++j) {
-            IMX_REQUIRE(col[o + j] < 0, "plan: observation column %d written twice", o + j);
-            col[o + j] = (k << 16) | j;
-        }
+        for (int h = 0; h < hist; ++h)
+            for (int j = 0; j < d; ++j) {
+                const int c = o + h * d + j;
+                IMX_REQUIRE(col[c] == -1, "plan: observation column %d written twice", c);
+                col[c] = h == hist - 1 ? ((k << 16) | j) : -2;  // -2: an older history slot (not computed)
+            }
     }
-    for (int c = 0; c < p->D; ++c) IMX_REQUIRE(col[c] >= 0, "plan: observation column %d not covered", c);
+    for (int c = 0; c < p->D; ++c) IMX_REQUIRE(col[c] != -1, "plan: observation column %d not covered", c);
     // ---- actions
     int acols = 0;
     for (int k = 0; k < p->nact; ++k) {
@@ -165,12 +172,15 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
     order.reserve(p->D);
     for (int pass = 0; pass < 2; ++pass)
         for (int c = 0; c < p->D; ++c) {
+            if (col[c] < 0) continue;  // history slot
             const int k = col[c] >> 16;
             const bool ray = w[p->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN;
             if (ray == (pass == 0)) order.push_back(c);
         }
     for (int c = 0; c < p->D; ++c)
-        if (w[p->obs_off + (col[c] >> 16) * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) p->n_ray_cols++;
+        if (col[c] >= 0 && w[p->obs_off + (col[c] >> 16) * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) p->n_ray_cols++;
+    p->DC = (int)order.size();  // computed columns (= D without history)
+    order.resize(p->D, 0);      // table keeps its D words
     w.insert(w.end(), order.begin(), order.end());
     // reward slots without a record (zero-weight terms): they still take part in the reset/log pass
     {
@@ -188,7 +198,7 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
     // per-column expansion (see step.hip: XC_*), 16-byte aligned, in `order`
     while (w.size() % 4) w.push_back(0);
     p->xcol_off = (int)w.size();
-    for (int i = 0; i < p->D; ++i) {
+    for (int i = 0; i < p->DC; ++i) {
         const int c = order[i], k = col[c] >> 16, j = col[c] & 0xFFFF;
         const size_t ro = (size_t)p->obs_off + (size_t)k * IMX_REC_WORDS;  // index: w reallocates while we append
         int32_t x[16] = {0};
@@ -203,6 +213,8 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
         if (op == IMX_O_HEIGHT_SCAN) {
             x[11] = w[(size_t)p->ray_off + 3 * j]; x[12] = w[(size_t)p->ray_off + 3 * j + 1]; x[13] = w[(size_t)p->ray_off + 3 * j + 2];
         }
+        x[14] = (op != IMX_O_EXTERNAL && w[ro + IMX_R_AUX1] > 1) ? w[ro + IMX_R_AUX1] : 1;  // history slots
+        x[15] = w[ro + IMX_R_DIM];                                                        // slot stride (term width)
         w.insert(w.end(), x, x + 16);
     }
     if (imx_device_count() > 0) {
@@ -229,7 +241,7 @@ PlanView imx_plan_view(const imx_plan* p) {
     v.nterm = p->nterm; v.nrew = p->nrew; v.nobs = p->nobs; v.nact = p->nact; v.nrew_all = p->nrew_all;
     v.term_off = p->term_off; v.rew_off = p->rew_off; v.obs_off = p->obs_off; v.act_off = p->act_off;
     v.ray_off = p->ray_off; v.col_off = p->col_off; v.order_off = p->order_off; v.n_ray_cols = p->n_ray_cols;
-    v.skip_off = p->skip_off; v.nskip = p->nskip; v.xcol_off = p->xcol_off;
+    v.skip_off = p->skip_off; v.nskip = p->nskip; v.xcol_off = p->xcol_off; v.DC = p->DC;
     v.max_ep_len = w[IMX_H_MAX_EP_LEN];
     v.step_dt = wf(w[IMX_H_STEP_DT]);
     v.max_ep_len_s = wf(w[IMX_H_MAX_EP_LEN_S]);

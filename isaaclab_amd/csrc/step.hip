@@ -475,7 +475,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
 // in flight: cell-table loads of all four, then the 48-byte triangle records of all four, then the Woop tests.
 #define IMX_OBS_ENVS_PER_BLOCK 4
 #define IMX_XCOL_WORDS 16
-enum { XC_COL = 0, XC_OP, XC_J, XC_FLAGS, XC_P0, XC_NLO, XC_NHI, XC_CLO, XC_CHI, XC_SCALE, XC_AUX, XC_RX, XC_RY, XC_RZ };
+enum { XC_COL = 0, XC_OP, XC_J, XC_FLAGS, XC_P0, XC_NLO, XC_NHI, XC_CLO, XC_CHI, XC_SCALE, XC_AUX, XC_RX, XC_RY, XC_RZ, XC_HIST, XC_HSTRIDE };
 
 struct XCol {
     int4 a, b, c, d;
@@ -491,7 +491,8 @@ IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restr
                        int64_t e, int D) {
     const int flags = x.a.w;
     if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
-        const int c = x.a.x;
+        // a term with a history window draws for its first (oldest-slot) columns, like rand_like on the (N, d) term value
+        const int c = x.a.x - (x.d.z - 1) * x.d.w;
         const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
         const float lo = f_of(x.b.y), hi = f_of(x.b.z);
         const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
@@ -541,7 +542,9 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
     const uint32_t step = (uint32_t)Bf.counters[2];
     const float pz = es[11];
     const float yw = es[16], yz = es[17], px = es[9], py = es[10];
-    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const bool fill_all = (corrupt & 2) != 0;
+    corrupt &= 1;
+    for (int i = threadIdx.x; i < P.DC; i += blockDim.x) {
         const XCol x = load_xcol(W, P.xcol_off, i);
         const int c = x.a.x, op = x.a.y, j = x.a.z, flags = x.a.w, aux = x.c.z;
         float v = 0.0f;
@@ -595,7 +598,21 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
             } break;
             default: break;
         }
-        Bf.obs[e * D + c] = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
+        const float vp = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
+        float* o = Bf.obs + e * D + c;  // newest slot
+        const int hist = x.d.z;
+        if (hist > 1) {
+            // CircularBuffer.append (utils/buffers/circular_buffer.py:107-135) on the window kept in the obs row itself: this
+            // lane owns element j of every slot.  Envs reset this step (or all, at env.reset) have zero pushes: every slot
+            // takes the first value; otherwise the window slides by one.
+            const int hs = x.d.w;
+            if (fill_all || Bf.reset_buf[e]) {
+                for (int h = 1; h < hist; ++h) o[-h * hs] = vp;
+            } else {
+                for (int h = hist - 1; h >= 1; --h) o[-h * hs] = o[-(h - 1) * hs];
+            }
+        }
+        *o = vp;
     }
 }
 
@@ -723,6 +740,7 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     IMX_REQUIRE(bf->obs && bf->counters, "imx_observations: null obs/counters buffer");
     IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w && st->root_pos_w, "root state missing");
     IMX_REQUIRE(!plan->needs_mesh || mesh, "plan has a height_scan term but no mesh was given");
+    IMX_REQUIRE(plan->DC == plan->D || bf->reset_buf, "imx_observations: observation history needs the reset mask (reset_buf)");
     const auto& w = plan->host;
     for (int k = 0; k < plan->nobs; ++k) {
         const int op = w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP];
@@ -744,7 +762,7 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     MeshView mv{};
     if (mesh) mv = mesh->v;
-    const int bs = plan->D <= 64 ? 64 : (plan->D <= 128 ? 128 : (plan->D <= 192 ? 192 : 256));  // one block per env
+    const int bs = plan->DC <= 64 ? 64 : (plan->DC <= 128 ? 128 : (plan->DC <= 192 ? 192 : 256));  // one block per env
     const PlanView pv = imx_plan_view(plan);
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));

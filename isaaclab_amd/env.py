@@ -606,7 +606,7 @@ class ManagerBasedRLEnv:
                 self._ext_obs[:, c:c + term.dim] = fn(self, **term.params).reshape(self.num_envs, -1)
                 c += term.dim
 
-    def _compute_observations(self) -> torch.Tensor:
+    def _compute_observations(self, fill_history: bool = False) -> torch.Tensor:
         if self._ext_funcs["obs"]:
             self._eval_external("obs")
         hits = None
@@ -617,7 +617,7 @@ class ManagerBasedRLEnv:
         check(self._lib.imx_observations(
             self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
             self.terrain.handle if self.terrain is not None else None, _lib.ptr(self._noise_u), self.noise_seed,
-            1 if self.plan.enable_corruption else 0, hits, _lib.current_stream(self.device)))
+            (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0), hits, _lib.current_stream(self.device)))
         return self._obs
 
     # ---- MDP operations ------------------------------------------------------------------------------------------
@@ -639,7 +639,13 @@ class ManagerBasedRLEnv:
             mask[ids] = True
             self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], mask,
                                       do_compute=False)
-        obs = self._compute_observations()
+        # ObservationManager.reset -> CircularBuffer.reset: the history windows of the reset envs restart from this observation
+        if env_ids is None:
+            obs = self._compute_observations(fill_history=True)
+        else:
+            self.reset_buf.zero_()
+            self.reset_buf[ids] = True
+            obs = self._compute_observations()
         return {"policy": obs}, self.extras
 
     def step(self, action: torch.Tensor):

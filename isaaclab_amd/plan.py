@@ -464,8 +464,13 @@ class PlanCompiler:
                 continue
             fn = func_name(tcfg["func"])
             p = dict(tcfg.get("params") or {})
-            if (tcfg.get("history_length") or 0) > 0 or (gcfg.get("history_length") or 0) > 0:
-                raise NotImplementedError(f"observation term '{name}': history buffers are not on the fused path")
+            # history (observation_manager.py:412-431): a group-level history_length overrides the terms'; the (N,H,d) window
+            # is flattened oldest-first into H*d columns (flatten_history_dim); kept in the obs buffer itself by the kernel
+            gh = gcfg.get("history_length")
+            hist = int(gh if gh is not None else (tcfg.get("history_length") or 0))
+            flat = gcfg.get("flatten_history_dim", True) if gh is not None else tcfg.get("flatten_history_dim", True)
+            if hist > 0 and not flat:
+                raise NotImplementedError(f"observation term '{name}': un-flattened history is not on the fused path")
             rec = dict(out=D)
             flags = 0
             known = tcfg.get("modifiers") is None
@@ -537,11 +542,14 @@ class PlanCompiler:
                     raise NotImplementedError(
                         f"observation term '{name}' ({fn}) is not on the fused path; give its width as cfg['_dim']")
                 n_ext_obs += dim
-            rec.update(dim=dim, flags=flags)
+                if hist > 0:
+                    raise NotImplementedError(f"observation term '{name}': history on a term evaluated in Python is not supported")
+            width = max(hist, 1) * dim
+            rec.update(dim=dim, flags=flags, aux1=hist)
             obs_recs.append(_rec(**rec))
-            obs_terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], dim=dim))
-            obs_dims.append((dim,))
-            D += dim
+            obs_terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], dim=width))
+            obs_dims.append((width,))
+            D += width
 
         # ---- assemble
         ray_off = blob.floats(ray_local.reshape(-1)) if ray_local is not None else 0

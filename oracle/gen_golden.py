@@ -266,12 +266,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
     def put(name, t):
         rec[name] = t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
-    meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=A, obs_dim=D,
+    meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=int(A), obs_dim=int(D),
                 step_dt=env.step_dt, max_episode_length=env.max_episode_length,
                 max_episode_length_s=env.max_episode_length_s, gravity_dir=feed.gravity_dir,
                 reward_terms=env.reward_manager.active_terms, termination_terms=env.termination_manager.active_terms,
                 obs_terms=env.observation_manager.active_terms["policy"],
-                obs_term_dims=[list(d) for d in env.observation_manager.group_obs_term_dim["policy"]])
+                obs_term_dims=[[int(x) for x in d] for d in env.observation_manager.group_obs_term_dim["policy"]])
     for n in STATIC:
         put("static/" + n, feed[n])
     if has_scan:
@@ -434,17 +434,33 @@ def main():
     from isaaclab_tasks.manager_based.locomotion.velocity.config.g1.agents.rsl_rl_ppo_cfg import G1RoughPPORunnerCfg
     from isaaclab_tasks.manager_based.locomotion.velocity.config.g1.rough_env_cfg import G1RoughEnvCfg
 
-    math_fixture()
-    mesh_fixture()
+    only = set(sys.argv[1:])  # `python oracle/gen_golden.py <task> ...` regenerates just those fixtures
+
+    def want(name):
+        return not only or name in only
+
+    if not only:
+        math_fixture()
+        mesh_fixture()
     verts, tris, ext = make_rough_terrain(2, 3, tile=4.0, border=3.0, seed=11)
     mesh = (verts, tris)
-    run_task("Isaac-Cartpole-v0", CartpoleEnvCfg(), CartpolePPORunnerCfg(), CARTPOLE, N=64, steps=3, seed=101)
-    run_task("Isaac-Velocity-Flat-Anymal-C-v0", AnymalCFlatEnvCfg(), AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64,
-             steps=3, seed=102)
-    run_task("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64,
-             steps=3, seed=103, mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
-    run_task("Isaac-Velocity-Rough-G1-v0", G1RoughEnvCfg(), G1RoughPPORunnerCfg(), G1, N=64, steps=3, seed=104,
-             mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
+    if want("Isaac-Cartpole-v0"):
+        run_task("Isaac-Cartpole-v0", CartpoleEnvCfg(), CartpolePPORunnerCfg(), CARTPOLE, N=64, steps=3, seed=101)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0"):
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0", AnymalCFlatEnvCfg(), AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64,
+                 steps=3, seed=102)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0-hist3"):
+        # observation history (ObservationGroupCfg.history_length, CircularBuffer): the flat task, 3-deep flattened history
+        hist_cfg = AnymalCFlatEnvCfg()
+        hist_cfg.observations.policy.history_length = 3
+        hist_cfg.observations.policy.flatten_history_dim = True
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0-hist3", hist_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=105)
+    if want("Isaac-Velocity-Rough-Anymal-C-v0"):
+        run_task("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64,
+                 steps=3, seed=103, mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
+    if want("Isaac-Velocity-Rough-G1-v0"):
+        run_task("Isaac-Velocity-Rough-G1-v0", G1RoughEnvCfg(), G1RoughPPORunnerCfg(), G1, N=64, steps=3, seed=104,
+                 mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
 
 
 if __name__ == "__main__":
