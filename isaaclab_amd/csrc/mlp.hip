@@ -13,7 +13,6 @@
 // v_mfma_f32_32x32x2_f32 is an exact f32 fma chain (one rounding per product): numerics = an fp32 GEMM with this
 // summation order.  PARITY UNPINNED like the rest of the rsl_rl restatement (checked against torch autograd in tests).
 #include <algorithm>
-#include <cstdlib>
 
 #include "imx_internal.h"
 
@@ -348,8 +347,7 @@ DwPlan dw_plan(int64_t M, int N, int K) {
     p.tn = (N + DW_T - 1) / DW_T;
     p.tk = (K + DW_T - 1) / DW_T;
     const int T = p.tn * p.tk;
-    static const int wg_per_cu = getenv("IMX_DW_WG_PER_CU") ? std::max(1, atoi(getenv("IMX_DW_WG_PER_CU"))) : 1;
-    int64_t S = std::max<int64_t>(1, (int64_t)g_num_cu * wg_per_cu / T);  // one 8-wave workgroup (80 KB of LDS) per CU
+    int64_t S = std::max<int64_t>(1, (int64_t)g_num_cu / T);  // one 8-wave workgroup (80 KB of LDS) per CU
     S = std::min<int64_t>(S, std::max<int64_t>(1, M / (2 * DW_BM)));  // at least two stages per split
     if (S >= 8) S &= ~(int64_t)7;
     p.rps = ((M + S - 1) / S + DW_BM - 1) / DW_BM * DW_BM;
