@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--terrain-tiles", type=int, nargs=2, default=(10, 20))
     ap.add_argument("--no-graph", action="store_true", help="eager rollout instead of one hipGraph replay per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-n", action="store_true", help="skip the 65 536-env launches of the observation kernel (they share "
+                    "its name and would skew a rocprofv3 --stats average taken over this command)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -323,7 +325,7 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
         # the same kernel at 16x the batch (65 536 envs): what the layout reaches once launch latency is amortised
-        if os.environ.get("IMX_BENCH_LARGE_N", "1") == "1" and args.task == TASK:
+        if os.environ.get("IMX_BENCH_LARGE_N", "1") == "1" and not args.no_large_n and args.task == TASK:
             try:
                 big_n = 65536
                 _, env_big, _ = build_env(args.task, big_n, device, 7, 1, tuple(args.terrain_tiles), mesh=env.terrain)

@@ -762,7 +762,10 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     MeshView mv{};
     if (mesh) mv = mesh->v;
-    const int bs = plan->DC <= 64 ? 64 : (plan->DC <= 128 ? 128 : (plan->DC <= 192 ? 192 : 256));  // one block per env
+    // one block per env; lanes take column i, i + blockDim, ...  Ray columns come first and are the long ones: when they
+    // fit in three waves the remaining (cheap) columns ride as a second trip of the first lanes instead of a fourth wave
+    int bs = plan->DC <= 64 ? 64 : (plan->DC <= 128 ? 128 : (plan->DC <= 192 ? 192 : 256));
+    if (plan->DC > 192 && plan->n_ray_cols > 0 && plan->n_ray_cols <= 192 && plan->DC <= 2 * 192) bs = 192;
     const PlanView pv = imx_plan_view(plan);
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
