@@ -461,3 +461,71 @@ def test_rollout_post_bootstrap_and_episode_stats(libimx):
     assert torch.equal(dones[:, 0].bool(), d) and torch.equal(dl, d.long())
     assert_close(stats, torch.stack([((cr0 + rew) * d).sum(), ((cl0 + 1) * d).sum(), d.sum().float()]), 1e-5, "episode stats")
     assert_close(cur_r, (cr0 + rew) * (~d), 1e-6, "running reward") and assert_close(cur_l, (cl0 + 1) * (~d), 0, "running length") is None
+
+
+def test_whole_update_matches_torch_reference(libimx):
+    """PPO.update end to end (minibatch gather, both MLPs forward/backward on the HIP kernels, loss, grad-norm clip, adaptive
+    KL learning rate, Adam, 2 epochs x 3 minibatches) against the same algorithm written with torch autograd, torch.optim.Adam
+    and the rsl_rl restatement (oracle/rsl_rl_oracle.py) on identical data and the identical minibatch permutation."""
+    import copy
+
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+    from oracle.rsl_rl_oracle import adaptive_lr, ppo_losses
+
+    T, N, D, A = 6, 50, 37, 5
+    torch.manual_seed(11)
+    pol = ActorCritic(D, D, A, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32], init_noise_std=0.8)
+    ref_pol = copy.deepcopy(pol).cuda()
+    kw = dict(num_learning_epochs=2, num_mini_batches=3, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
+              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    alg = PPO(pol, device="cuda:0", **kw)
+    alg.init_storage("rl", N, T, (D,), (0,), (A,))  # no privileged observations: the critic sees the policy observations
+    st = alg.storage
+    g = torch.Generator().manual_seed(5)
+    st.observations.copy_(torch.randn(T, N, D, generator=g))
+    with torch.no_grad():
+        mu = ref_pol.actor(st.observations.flatten(0, 1)).view(T, N, A)
+        val = ref_pol.critic(st.observations.flatten(0, 1)).view(T, N, 1)
+    sigma = ref_pol.std.detach().expand(T, N, A).contiguous()
+    act = mu + sigma * torch.randn(T, N, A, generator=g).cuda()
+    st.mu.copy_(mu); st.sigma.copy_(sigma); st.actions.copy_(act); st.values.copy_(val)
+    st.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+    st.returns.copy_(val + 0.3 * torch.randn(T, N, 1, generator=g).cuda())
+    st.advantages.copy_(torch.randn(T, N, 1, generator=g))
+    st.step = T
+    flat = lambda x: x.flatten(0, 1)  # noqa: E731
+    data = [flat(x).clone() for x in (st.observations, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob, st.mu, st.sigma)]
+
+    # ---- product path
+    torch.manual_seed(99)  # seeds the randperm of the minibatch generator
+    alg.update()
+    torch.cuda.synchronize()
+
+    # ---- reference: same permutation, torch autograd + clip_grad_norm_ + Adam + the upstream adaptive-LR rule
+    torch.manual_seed(99)
+    M = T * N // kw["num_mini_batches"]
+    perm = torch.randperm(kw["num_mini_batches"] * M, device="cuda:0")
+    opt = torch.optim.Adam(ref_pol.parameters(), lr=kw["learning_rate"])
+    lr = kw["learning_rate"]
+    for _ in range(kw["num_learning_epochs"]):
+        for i in range(kw["num_mini_batches"]):
+            idx = perm[i * M:(i + 1) * M]
+            obs, a_, v_old, adv, ret, logp_old, mu_old, sg_old = (x[idx] for x in data)
+            mu_b = ref_pol.actor(obs)
+            s, v, e, kl = ppo_losses(mu_b, ref_pol.std.expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(obs), v_old,
+                                     kw["clip_param"], True)
+            lr = adaptive_lr(lr, float(kl), kw["desired_kl"])
+            for gr in opt.param_groups:
+                gr["lr"] = lr
+            loss = s + kw["value_loss_coef"] * v - kw["entropy_coef"] * e
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref_pol.parameters(), kw["max_grad_norm"])
+            opt.step()
+    assert abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr), (alg.learning_rate, lr)
+    for (name, p), q in zip(pol.named_parameters(), ref_pol.parameters()):
+        err = float((p - q).abs().max())
+        assert err <= 2e-5 * max(1.0, float(q.abs().max())), f"{name}: max err {err:.2e} after {kw['num_learning_epochs'] * kw['num_mini_batches']} optimiser steps"
+    stats = alg.loss_dict()
+    assert all(np.isfinite(x) for x in stats.values())
