@@ -277,3 +277,39 @@ def test_runner_learn_modes(mode, tmp_path):
     a = policy(env.get_observations()[0])
     assert a.shape == (64, 12) and torch.isfinite(a).all()
     assert hasattr(runner.alg.policy, "actor") and hasattr(runner.alg.policy, "critic") and not runner.alg.policy.is_recurrent
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_rollout_storage_is_self_consistent(use_graph):
+    """After one collect() through the fused path (imx_mlp_infer, imx_policy_act, env kernels, imx_rollout_post; eager
+    and as a hipGraph) every stored transition is consistent with the modules: mu = actor(obs), value = critic(obs),
+    log-prob = Normal(mu, sigma).log_prob(action), obs[t+1] = what env.step returned, dones = terminated | time-outs."""
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    env = RslRlVecEnvWrapper(ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0")))
+    cfg = dict(g.fixture["agent"], num_steps_per_env=8)
+    runner = OnPolicyRunner(env, cfg, log_dir=None, device="cuda:0", use_graph=use_graph)
+    assert runner._fusable()
+    runner.train_mode()
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+    env.episode_length_buf[::7] = int(env.max_episode_length) - 3  # some time-outs inside the rollout
+    for _ in range(2):  # the second collect replays the captured graph
+        runner.collect()
+    torch.cuda.synchronize()
+    st, pol = runner.alg.storage, runner.alg.policy
+    T = runner.num_steps_per_env
+    with torch.no_grad():
+        for t in range(T):
+            obs = st.observations[t]
+            assert_close(st.mu[t], pol.actor(obs), 1e-5, f"mu[{t}]")
+            assert_close(st.values[t], pol.critic(obs), 1e-5, f"values[{t}]")
+            assert torch.equal(st.sigma[t], pol.std.expand_as(st.mu[t]))
+            logp = torch.distributions.Normal(st.mu[t], st.sigma[t]).log_prob(st.actions[t]).sum(-1, keepdim=True)
+            assert_close(st.actions_log_prob[t], logp, 1e-4, f"log-prob[{t}]")
+            z = (st.actions[t] - st.mu[t]) / st.sigma[t]
+            assert float(z.abs().max()) < 6.0 and 0.8 < float(z.std()) < 1.2  # a ~ N(mu, sigma)
+        assert_close(runner.last_obs, env.unwrapped._obs, 0, "last obs")
+    assert st.dones.sum() > 0 and set(st.dones.unique().tolist()) <= {0, 1}
+    assert torch.isfinite(st.rewards).all() and float(st.rewards.abs().sum()) > 0
