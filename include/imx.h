@@ -385,7 +385,7 @@ int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int
                   const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                   float* const* out_d, imx_stream_t stream);
 
-/* Output layer forward, A <= 16 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K).
+/* Output layer forward, A <= 64 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K).
  * elu_in_place != 0: h_d holds the PRE-activation output of the layer below; h <- ELU(h) (aten elu, alpha = elu_alpha) is
  * applied on the way in and written back in place, so that layer needs no separate activation pass. */
 int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,

@@ -356,11 +356,11 @@ DwPlan dw_plan(int64_t M, int N, int K) {
 }
 
 // ------------------------------------------------------------------------------------------------------------- head
-constexpr int HEAD_A = 16;  // widest output layer handled (actions / value)
+constexpr int HEAD_A = 64;  // widest output layer handled (actions / value): 37 action means of a humanoid fit
 
 // ELU_IN: h holds the PRE-activation output of the layer below; ELU is applied on the way in and written back in place
 // (every element is read by exactly one lane), which saves that layer's separate activation pass.
-template <bool ELU_IN>
+template <bool ELU_IN, int AMAX>
 __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float* __restrict__ h, int64_t ldh,
                                                   const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y,
                                                   float alpha) {
@@ -370,9 +370,9 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
     const int q = threadIdx.x & 3;
     const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool live = row < M;
-    float acc[HEAD_A];
+    float acc[AMAX];
 #pragma unroll
-    for (int o = 0; o < HEAD_A; ++o) acc[o] = 0.0f;
+    for (int o = 0; o < AMAX; ++o) acc[o] = 0.0f;
     float* hr = h + (live ? row : 0) * ldh;
     for (int k = 4 * q; k < K; k += 16) {  // the 4 lanes of a sample read one 64-byte run per trip
         float4 hv = *reinterpret_cast<const float4*>(hr + k);
@@ -384,14 +384,14 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
             if (live) *reinterpret_cast<float4*>(hr + k) = hv;
         }
 #pragma unroll
-        for (int o = 0; o < HEAD_A; ++o)
+        for (int o = 0; o < AMAX; ++o)
             if (o < A) {
                 const float4 wv = *reinterpret_cast<const float4*>(sW + o * K + k);
                 acc[o] = fmaf(hv.w, wv.w, fmaf(hv.z, wv.z, fmaf(hv.y, wv.y, fmaf(hv.x, wv.x, acc[o]))));
             }
     }
 #pragma unroll
-    for (int o = 0; o < HEAD_A; ++o)
+    for (int o = 0; o < AMAX; ++o)
         if (o < A) {
             float v = acc[o];
             v += __shfl_xor(v, 1);
@@ -403,22 +403,28 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
 // One wave per 32 in-features.  Per block of 32 samples: dX = dY W on the matrix core (A <= 32 reduction steps of 2), the
 // accumulator tile (sample rows on the registers, in-feature on the lane) times ELU'(h) -> d of the layer below, and the
 // same h registers as the B operand of dW += dY^T h.
+// AB = 32-output blocks of the dW accumulator (1: A <= 32, 2: A <= 64).
+template <int AB>
 __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const float* __restrict__ dY, const float* __restrict__ h,
                                                     int64_t ldh, const float* __restrict__ W, float alpha, int has_act,
                                                     float* __restrict__ dprev, float* __restrict__ part, float* __restrict__ part_db) {
     const int lane = threadIdx.x & 63, kb = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
     const int kc = kb * 32 + r;  // this lane's in-feature
     const int steps = (A + 1) >> 1;
-    float wreg[HEAD_A / 2];
+    float wreg[AB * 16];
 #pragma unroll
-    for (int s = 0; s < HEAD_A / 2; ++s) {
+    for (int s = 0; s < AB * 16; ++s) {
         const int o = 2 * s + half;
         wreg[s] = (s < steps && o < A) ? W[o * K + kc] : 0.0f;
     }
-    f32x16 wacc;
+    f32x16 wacc[AB];
+    float dbacc[AB];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) wacc[q] = 0.0f;
-    float dbacc = 0.0f;
+    for (int b = 0; b < AB; ++b) {
+        dbacc[b] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wacc[b][q] = 0.0f;
+    }
     const int64_t nblk = (M + 31) / 32;
     for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
         const int64_t m0 = rb * 32;
@@ -432,7 +438,7 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
 #pragma unroll
         for (int q = 0; q < 16; ++q) dx[q] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < HEAD_A / 2; ++s)
+        for (int s = 0; s < AB * 16; ++s)
             if (s < steps) {
                 const int o = 2 * s + half;
                 const int64_t row = m0 + r;
@@ -450,20 +456,27 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int64_t row = m0 + acc_row(q, half);
-            const float av = (row < M && r < A) ? dY[row * A + r] : 0.0f;
-            wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[q], wacc, 0, 0, 0);
-            dbacc += av;
+#pragma unroll
+            for (int b = 0; b < AB; ++b) {
+                const int o = 32 * b + r;
+                const float av = (row < M && o < A) ? dY[row * A + o] : 0.0f;
+                wacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[q], wacc[b], 0, 0, 0);
+                dbacc[b] += av;
+            }
         }
     }
     float* p = part + (size_t)blockIdx.x * A * K;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int o = acc_row(q, half);
-        if (o < A) p[o * K + kc] = wacc[q];
-    }
-    if (kb == 0) {
-        const float tot = dbacc + __shfl_xor(dbacc, 32);
-        if (half == 0 && r < A) part_db[(size_t)blockIdx.x * A + r] = tot;
+    for (int b = 0; b < AB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int o = 32 * b + acc_row(q, half);
+            if (o < A) p[o * K + kc] = wacc[b][q];
+        }
+        if (kb == 0) {
+            const float tot = dbacc[b] + __shfl_xor(dbacc[b], 32);
+            if (half == 0 && 32 * b + r < A) part_db[(size_t)blockIdx.x * A + 32 * b + r] = tot;
+        }
     }
 }
 
@@ -607,12 +620,14 @@ extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh
     IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_fwd: %d outputs (1..%d supported; wider layers are library GEMMs)", A, HEAD_A);
     IMX_REQUIRE(K >= 16 && K % 16 == 0 && K <= 2048 && ldh >= K && ldh % 4 == 0 && aligned16(h_d),
                 "imx_mlp_head_fwd: in-features %d (pitch %lld) must be a multiple of 16, 16-byte aligned rows", K, (long long)ldh);
-    if (elu_in_place)
-        hipLaunchKernelGGL((k_head_fwd<true>), dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M,
-                           K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha);
-    else
-        hipLaunchKernelGGL((k_head_fwd<false>), dim3((unsigned)((M + 63) / 64)), dim3(256), (size_t)A * K * sizeof(float), (hipStream_t)stream, M,
-                           K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha);
+    IMX_REQUIRE((size_t)A * K * sizeof(float) <= 64 * 1024, "imx_mlp_head_fwd: %d x %d weights do not fit the 64 KB of LDS used", A, K);
+    const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+    const size_t lds = (size_t)A * K * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define IMX_HEAD_FWD(E, AM) hipLaunchKernelGGL((k_head_fwd<E, AM>), grid, block, lds, st, M, K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha)
+    if (A <= 16) { if (elu_in_place) IMX_HEAD_FWD(true, 16); else IMX_HEAD_FWD(false, 16); }
+    else { if (elu_in_place) IMX_HEAD_FWD(true, HEAD_A); else IMX_HEAD_FWD(false, HEAD_A); }
+#undef IMX_HEAD_FWD
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -629,8 +644,12 @@ extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, cons
     float* part = (float*)scratch_d;
     float* part_db = part + (size_t)G * A * K;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)G), dim3((unsigned)(K / 32 * 64)), 0, st, M, K, A, dY_d, h_d, ldh, W_d, elu_alpha,
-                       has_activation, dprev_d, part, part_db);
+    if (A <= 32)
+        hipLaunchKernelGGL((k_head_bwd<1>), dim3((unsigned)G), dim3((unsigned)(K / 32 * 64)), 0, st, M, K, A, dY_d, h_d, ldh, W_d, elu_alpha,
+                           has_activation, dprev_d, part, part_db);
+    else
+        hipLaunchKernelGGL((k_head_bwd<2>), dim3((unsigned)G), dim3((unsigned)(K / 32 * 64)), 0, st, M, K, A, dY_d, h_d, ldh, W_d, elu_alpha,
+                           has_activation, dprev_d, part, part_db);
     IMX_HIP(hipGetLastError());
     return reduce_or_defer("imx_mlp_head_bwd", (int64_t)A * K, G, part, dW_d, A, part_db, db_d, st);
 }

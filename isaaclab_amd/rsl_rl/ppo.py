@@ -184,7 +184,7 @@ class FusedInference:
                                   self._alpha, out_p, _lib.current_stream(x.device)))
 
 
-HEAD_MAX_OUT = 16  # imx_mlp_head_*: output layers up to 16 wide (action means, value)
+HEAD_MAX_OUT = 64  # imx_mlp_head_*: output layers up to 64 wide (action means, value)
 
 
 def _is_head(lin: nn.Linear, x: torch.Tensor) -> bool:

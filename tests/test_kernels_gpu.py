@@ -300,7 +300,7 @@ def test_deferred_reductions_match_immediate(libimx):
     libimx.imx_reduce_batch_destroy(h)
 
 
-@pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5)])
+@pytest.mark.parametrize("M,K,A", [(24576, 128, 12), (24576, 128, 1), (1000, 256, 16), (37, 32, 5), (4099, 128, 37), (300, 64, 64)])
 def test_mlp_head_matches_autograd(libimx, M, K, A):
     """imx_mlp_head_fwd / imx_mlp_head_bwd against torch (fp64) for the layer  y = ELU(z) W^T + b."""
     from isaaclab_amd import _lib
@@ -339,7 +339,7 @@ def test_mlp_head_matches_autograd(libimx, M, K, A):
     _lib.check(libimx.imx_mlp_head_bwd(M, K, A, dY.data_ptr(), h.data_ptr(), K, W.data_ptr(), 0.0, 0, dprev.data_ptr(), dW.data_ptr(),
                                        db.data_ptr(), scratch.data_ptr(), nbytes, st))
     assert float((dprev.double() - dY.double() @ W.double()).abs().max()) <= 1e-5
-    assert libimx.imx_mlp_head_fwd(M, K, 17, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st) != 0
+    assert libimx.imx_mlp_head_fwd(M, K, 65, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st) != 0
 
 
 @pytest.mark.parametrize("fused_norm", [False, True])
