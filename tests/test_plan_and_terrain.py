@@ -89,3 +89,38 @@ def test_term_compiler_errors_follow_the_reference():
     assert p.n_ext_rew == 1 and p.reward_terms[-1].external == "my_pkg.mdp:my_reward"
     # zero-weight terms keep their slot but emit no record (reward_manager.py:145)
     assert p.blob[planmod.H["NREW"]] == len([t for t in p.reward_terms if t.weight != 0.0])
+
+
+def test_policy_is_exportable_like_the_reference_exporter(tmp_path):
+    """SURVEY 8f row 3, export compatibility: what isaaclab_rl/rsl_rl/exporter.py::_TorchPolicyExporter does with a policy
+    (deepcopy of ``policy.actor``, ``policy.is_recurrent``, normalizer in front, torch.jit.script, save / load) works on this
+    ActorCritic after its parameters were re-homed into the flat bucket, and the normalizer module scripts too."""
+    import copy
+
+    import torch
+
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import FlatParams
+
+    torch.manual_seed(0)
+    pol = ActorCritic(48, 48, 12, actor_hidden_dims=[128, 128, 128], critic_hidden_dims=[128, 128, 128])
+    FlatParams(pol)  # parameters become views of one bucket, as inside PPO
+    assert not pol.is_recurrent and hasattr(pol, "actor")
+
+    class Exporter(torch.nn.Module):  # same structure as the reference's exporter module (non-recurrent branch)
+        def __init__(self, policy):
+            super().__init__()
+            self.actor = copy.deepcopy(policy.actor)
+            self.normalizer = torch.nn.Identity()
+
+        def forward(self, x):
+            return self.actor(self.normalizer(x))
+
+    ex = Exporter(pol)
+    ex.to("cpu")
+    scripted = torch.jit.script(ex)
+    path = str(tmp_path / "policy.pt")
+    scripted.save(path)
+    loaded = torch.jit.load(path)
+    x = torch.randn(5, 48)
+    assert torch.equal(loaded(x), pol.actor(x)) and torch.equal(pol.act_inference(x), pol.actor(x))
