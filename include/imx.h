@@ -419,6 +419,13 @@ int imx_reset_events(int64_t N, int64_t J, const uint8_t* reset_mask_d, const fl
 int imx_push_velocity(int64_t N, const uint8_t* mask_d, const float* ranges12, const float* uniforms_d, uint64_t seed,
                       const int32_t* step_counter_d, float* root_vel_w_d, imx_stream_t stream);
 
+/* apply_external_force_torque (events.py:764-791): forces / torques ~ U(range) for bodies body_ids_d[0..num_ids) (device int32;
+ * NULL = all num_bodies) of the masked envs, written into the (N, num_bodies, 3) buffers set_external_force_and_torque fills.
+ * ranges4 (HOST) = force lo,hi, torque lo,hi; uniforms_d: optional (2, N, nb, 3), forces first. */
+int imx_external_force_torque(int64_t N, int64_t num_bodies, const uint8_t* mask_d, const int32_t* body_ids_d, int64_t num_ids,
+                              const float* ranges4, const float* uniforms_d, uint64_t seed, const int32_t* step_counter_d,
+                              float* forces_d, float* torques_d, imx_stream_t stream);
+
 /* terrain_levels_vel (isaaclab_tasks/.../velocity/mdp/curriculums.py:26-55) + TerrainImporter.update_env_origins
  * (terrains/terrain_importer.py:307-326): move up when the robot walked more than half a tile, down when less than half
  * the commanded distance; levels past the last are replaced by rand_levels_d[e] (randint_like; NULL -> in-kernel draw);

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "imx_reset_events": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_uint64, c_void_p] + [c_void_p] * 4
                          + [c_void_p]),
     "imx_push_velocity": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "imx_external_force_torque": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
     "imx_terrain_levels": (c_int, [c_int64, c_int64, c_int64] + [c_void_p] * 5 + [c_float, c_float, c_void_p, c_uint64, c_void_p]
                            + [c_void_p] * 3 + [c_void_p]),
     "imx_mlp_scratch_bytes": (c_size_t, [c_int64, c_int, c_int]),

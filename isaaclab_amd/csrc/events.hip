@@ -96,6 +96,27 @@ k_push_velocity(int64_t N, PushCfg c, const uint8_t* __restrict__ mask, const fl
     }
 }
 
+// apply_external_force_torque (events.py:764-791): U(range) forces and torques on the selected bodies of the masked envs
+__global__ void __launch_bounds__(256)
+k_external_force_torque(int64_t N, int NB, int nb, const int32_t* __restrict__ body_ids, float f_lo, float f_hi, float t_lo, float t_hi,
+                        const uint8_t* __restrict__ mask, const float* __restrict__ U, uint64_t seed, const int32_t* __restrict__ step_d,
+                        float* __restrict__ forces, float* __restrict__ torques) {
+    const uint32_t step = step_d ? (uint32_t)step_d[0] : 0u;
+    const int64_t per_env = (int64_t)nb * 3, total = N * per_env;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / per_env;
+        const int q = (int)(i - e * per_env), b = q / 3, c = q - 3 * b;
+        if (mask && !mask[e]) continue;
+        const int body = body_ids ? body_ids[b] : b;
+        // uniforms: (2, N, nb, 3) -- forces first, torques second, like the two sample_uniform calls of the reference
+        const float uf = U ? U[i] : uniform01(seed + 4242u, step, (uint64_t)i);
+        const float ut = U ? U[total + i] : uniform01(seed + 4243u, step, (uint64_t)i);
+        const int64_t o = (e * NB + body) * 3 + c;
+        forces[o] = uf * (f_hi - f_lo) + f_lo;
+        torques[o] = ut * (t_hi - t_lo) + t_lo;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_terrain_levels(int64_t N, int R, int C, const uint8_t* __restrict__ mask, const float* __restrict__ root_pos,
                  const float* __restrict__ command, const float* __restrict__ terrain_origins, const int64_t* __restrict__ types,
@@ -174,6 +195,19 @@ extern "C" int imx_push_velocity(int64_t N, const uint8_t* mask_d, const float* 
     const unsigned grid = (unsigned)std::min<int64_t>((N * 6 + 255) / 256, 4096);
     hipLaunchKernelGGL(k_push_velocity, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, c, mask_d, uniforms_d, seed, step_counter_d,
                        root_vel_w_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_external_force_torque(int64_t N, int64_t num_bodies, const uint8_t* mask_d, const int32_t* body_ids_d, int64_t num_ids,
+                                         const float* ranges4, const float* uniforms_d, uint64_t seed, const int32_t* step_counter_d,
+                                         float* forces_d, float* torques_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && num_bodies > 0 && ranges4 && forces_d && torques_d, "imx_external_force_torque: bad arguments");
+    const int64_t nb = body_ids_d ? num_ids : num_bodies;
+    IMX_REQUIRE(nb > 0 && nb <= num_bodies, "imx_external_force_torque: %lld selected bodies of %lld", (long long)nb, (long long)num_bodies);
+    const unsigned grid = (unsigned)std::min<int64_t>((N * nb * 3 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_external_force_torque, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, (int)num_bodies, (int)nb, body_ids_d,
+                       ranges4[0], ranges4[1], ranges4[2], ranges4[3], mask_d, uniforms_d, seed, step_counter_d, forces_d, torques_d);
     IMX_HIP(hipGetLastError());
     return 0;
 }

@@ -90,6 +90,28 @@ class ResetEvents:
             self._step += 1
 
 
+class ExternalForceTorque:
+    """``apply_external_force_torque`` (events.py:764-791) on a subset of bodies, masked."""
+
+    def __init__(self, num_envs: int, num_bodies: int, device, force_range, torque_range, body_ids=None, seed: int = 0):
+        self.N, self.NB, self.device = int(num_envs), int(num_bodies), torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ExternalForceTorque needs a GPU: libimx has no CPU path")
+        self._ranges = (ctypes.c_float * 4)(float(force_range[0]), float(force_range[1]), float(torque_range[0]), float(torque_range[1]))
+        self.body_ids = None if body_ids is None else torch.as_tensor(list(body_ids), dtype=torch.int32, device=self.device)
+        self.seed = int(seed)
+        self._step = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def apply(self, mask, forces, torques, uniforms=None):
+        """Rewrites rows ``mask != 0`` (None = all) of forces / torques (N, num_bodies, 3) for the selected bodies."""
+        p = _lib.ptr
+        n = 0 if self.body_ids is None else int(self.body_ids.numel())
+        check(lib().imx_external_force_torque(self.N, self.NB, p(mask), p(self.body_ids), n, self._ranges, p(uniforms), self.seed,
+                                              self._step.data_ptr(), p(forces), p(torques), _lib.current_stream(self.device)))
+        if uniforms is None:
+            self._step += 1
+
+
 class TerrainCurriculum:
     """``terrain_levels_vel`` + ``TerrainImporter.update_env_origins`` (levels, origins updated in place)."""
 

@@ -58,6 +58,11 @@ class FakeAsset:
     def write_root_velocity_to_sim(self, vel, env_ids=None):
         self.writes["root_vel"] = (vel.clone(), env_ids.clone())
 
+    num_bodies = 17
+
+    def set_external_force_and_torque(self, forces, torques, env_ids=None, body_ids=None):
+        self.writes["ext"] = (forces.clone(), torques.clone(), env_ids.clone(), body_ids)
+
     def write_joint_state_to_sim(self, pos, vel, env_ids=None):
         self.writes["joint_pos"] = (pos.clone(), env_ids.clone())
         self.writes["joint_vel"] = (vel.clone(), env_ids.clone())
@@ -122,6 +127,20 @@ def main():
     torch.manual_seed(105)
     rec["push/u"] = scatter(N, ids, torch.rand(k, 6)).numpy()
     rec["push/vel_out"] = scatter(N, ids, asset.writes["root_vel"][0]).numpy()
+
+    # ---- apply_external_force_torque (velocity_env_cfg.py:177-185 uses zero ranges on the base; non-zero here, 3 of 17 bodies)
+    body_cfg = SceneEntityCfg("robot")
+    body_cfg.body_ids = [0, 5, 11]
+    torch.manual_seed(107)
+    ref_events.apply_external_force_torque(env, ids, (-2.0, 3.0), (-0.5, 0.7), body_cfg)
+    torch.manual_seed(107)
+    rec["ext/u_force"] = scatter(N, ids, torch.rand(k, 3, 3)).numpy()
+    rec["ext/u_torque"] = scatter(N, ids, torch.rand(k, 3, 3)).numpy()
+    fo, to, eids, bids = asset.writes["ext"]
+    assert torch.equal(eids, ids) and bids == [0, 5, 11]
+    rec["ext/forces"], rec["ext/torques"] = scatter(N, ids, fo).numpy(), scatter(N, ids, to).numpy()
+    rec["ext/body_ids"] = np.array([0, 5, 11], dtype=np.int32)
+    rec["ext/ranges"] = np.array([-2.0, 3.0, -0.5, 0.7], dtype=np.float32)
 
     # ---- terrain_levels_vel + TerrainImporter.update_env_origins
     R, C = 10, 20

@@ -94,6 +94,10 @@ def test_events_oracle_matches_reference():
         assert_close(v[mask], t(f"joints_{tag}/vel_out")[mask], 1e-6, f"joint vel {tag}")
     pv = eo.push_by_setting_velocity(t("root_vel_w"), meta["push_range"], t("push/u"))
     assert_close(pv[mask], t("push/vel_out")[mask], 1e-6, "push")
+    r4 = z["ext/ranges"]
+    fo, to = eo.apply_external_force_torque((float(r4[0]), float(r4[1])), (float(r4[2]), float(r4[3])), t("ext/u_force"), t("ext/u_torque"))
+    assert_close(fo[mask], t("ext/forces")[mask], 1e-6, "external forces")
+    assert_close(to[mask], t("ext/torques")[mask], 1e-6, "external torques")
     lv, og, mean = eo.terrain_levels_vel(mask, t("curr/root_pos_w"), t("curr/env_origins_in"), t("curr/command"), t("curr/terrain_origins"),
                                          t("curr/levels_in"), t("curr/types"), meta["terrain_size"], meta["max_episode_length_s"],
                                          t("curr/randint"))

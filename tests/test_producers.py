@@ -251,6 +251,29 @@ def test_reset_events_in_kernel_generator_properties():
 
 
 @pytest.mark.gpu
+def test_external_force_torque_hip_matches_reference():
+    from isaaclab_amd.events import ExternalForceTorque
+
+    z, meta = _events_golden()
+    N = meta["N"]
+    c = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    r = z["ext/ranges"]
+    ids = z["ext/body_ids"].tolist()
+    ev = ExternalForceTorque(N, 17, "cuda", (float(r[0]), float(r[1])), (float(r[2]), float(r[3])), body_ids=ids)
+    forces, torques = torch.full((N, 17, 3), 9.0, device="cuda"), torch.full((N, 17, 3), 9.0, device="cuda")
+    U = torch.stack([c("ext/u_force"), c("ext/u_torque")]).contiguous()
+    mb = c("mask")
+    ev.apply(mb.to(torch.uint8), forces, torques, uniforms=U)
+    assert_close(forces[mb][:, ids], c("ext/forces")[mb], 1e-6, "forces")
+    assert_close(torques[mb][:, ids], c("ext/torques")[mb], 1e-6, "torques")
+    other = [b for b in range(17) if b not in ids]
+    assert bool((forces[:, other] == 9.0).all()) and bool((forces[~mb] == 9.0).all()) and bool((torques[~mb] == 9.0).all())
+    ev.apply(None, forces, torques)  # in-kernel generator, every env
+    assert float(forces[:, ids].min()) >= r[0] and float(forces[:, ids].max()) <= r[1] and float(forces[:, ids].std()) > 1.0
+    assert float(torques[:, ids].min()) >= r[2] and float(torques[:, ids].max()) <= r[3]
+
+
+@pytest.mark.gpu
 def test_terrain_curriculum_hip_matches_reference():
     from isaaclab_amd.events import TerrainCurriculum
 
