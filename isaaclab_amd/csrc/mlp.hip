@@ -832,6 +832,150 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
     }
 }
 
+// ---- 16-sample variant (v_mfma_f32_16x16x4_f32) for small batches: twice the workgroups (and half the LDS each) when
+// 32-sample tiles would leave half of the CUs idle (<= 2048 envs for two networks on 256 CUs).  Same structure as above:
+// NBW = 16-column blocks per wave (8, 4, 2, 1), a sub-group is 32 reduction indices = 8 MFMA steps per block (lane quarter
+// kq supplies k = 32s + 4kq + {0..3} and 32s + 16 + 4kq + {0..3}: the four quarters cover one 128-byte weight line).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int INF16_ROWS = 16;
+
+template <int NBW>
+__device__ __forceinline__ void infer_layer16(const float* __restrict__ sIn, int K, const float* __restrict__ W, int ldw,
+                                              const float* __restrict__ bias, int N, bool elu, float alpha, float* __restrict__ sOut,
+                                              float* __restrict__ gOut, int64_t m0, int64_t M) {
+    constexpr int GS = NBW >= 8 ? 1 : (NBW == 4 ? 2 : 4);  // sub-groups per group: >= 64 MFMAs (2048 cycles) per group
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+    f32x4 acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[b][q] = 0.0f;
+    const int nsub = (K + 31) >> 5;
+    const int ng = (nsub + GS - 1) / GS;
+    const float* wrow[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int n = (w + 4 * b) * 16 + j;
+        wrow[b] = W + (size_t)(n < N ? n : N - 1) * ldw + 4 * kq;
+    }
+    const float* arow = sIn + j * INF_PITCH + 4 * kq;
+    float4 Pa[GS][2], Qa[GS][2], Pb[NBW][GS][2], Qb[NBW][GS][2];
+    auto load = [&](float4 (&a)[GS][2], float4 (&bq)[NBW][GS][2], int g) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const int sg = g * GS + u;
+            const int sc = sg < nsub ? sg : nsub - 1;
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                bq[b][u][0] = *reinterpret_cast<const float4*>(wrow[b] + 32 * sc);
+                bq[b][u][1] = *reinterpret_cast<const float4*>(wrow[b] + 32 * sc + 16);
+            }
+            float4 v0 = *reinterpret_cast<const float4*>(arow + 32 * sc);
+            float4 v1 = *reinterpret_cast<const float4*>(arow + 32 * sc + 16);
+            if (sg >= nsub) { v0 = make_float4(0.f, 0.f, 0.f, 0.f); v1 = v0; }
+            a[u][0] = v0;
+            a[u][1] = v1;
+        }
+    };
+    auto mult = [&](const float4 (&a)[GS][2], const float4 (&bq)[NBW][GS][2]) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GS; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].x, bq[b][u][i].x, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].y, bq[b][u][i].y, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].z, bq[b][u][i].z, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].w, bq[b][u][i].w, acc[b], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load(Pa, Pb, 0);
+    int g = 0;
+    for (; g + 1 < ng; g += 2) {
+        load(Qa, Qb, g + 1);
+        mult(Pa, Pb);
+        load(Pa, Pb, g + 2 < ng ? g + 2 : ng - 1);
+        mult(Qa, Qb);
+    }
+    if (g < ng) mult(Pa, Pb);
+    // epilogue: 16x16 accumulator: column = lane & 15, row = (lane >> 4) * 4 + register
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int n = (w + 4 * b) * 16 + j;
+        if (n >= N) continue;
+        const float bv = bias[n];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = kq * 4 + q;
+            float v = acc[b][q] + bv;
+            if (elu) v = v > 0.0f ? v : (expf(v) - 1.0f) * alpha;
+            if (sOut) sOut[row * INF_PITCH + n] = v;
+            else if (m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a) {
+    extern __shared__ float smem[];  // two activation buffers of INF16_ROWS x INF_PITCH floats
+    float* buf0 = smem;
+    float* buf1 = smem + INF16_ROWS * INF_PITCH;
+    const int which = blockIdx.x / a.tiles;
+    const InferNet& net = a.net[which];
+    const int64_t m0 = (int64_t)(blockIdx.x - which * a.tiles) * INF16_ROWS;
+    const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        float v[4][INF_MAXD / 64];  // wave w: rows w, w+4, w+8, w+12; all loads before the first LDS store
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = w + 4 * rr;
+            const float* src = a.X + (m0 + row < a.M ? m0 + row : 0) * a.ldx;
+#pragma unroll
+            for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                const int c = lane + 64 * cc;
+                const float x = src[c < K0 ? c : 0];
+                v[rr][cc] = (c < K0 && m0 + row < a.M) ? x : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = w + 4 * rr;
+#pragma unroll
+            for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
+            }
+        }
+    }
+    __syncthreads();
+    float* in = buf0;
+    float* out = buf1;
+    for (int l = 0; l < net.nlayers; ++l) {
+        const int K = net.dim[l], N = net.dim[l + 1];
+        const bool last = l == net.nlayers - 1;
+        const int nbw = ((N + 15) / 16 + 3) / 4;  // 16-column blocks per wave
+        float* so = last ? nullptr : out;
+        if (!last) {
+            const int Np = (N + 31) & ~31;
+            for (int i = threadIdx.x; i < INF16_ROWS * (Np - N); i += blockDim.x) {
+                const int row = i / (Np - N), col = N + i - row * (Np - N);
+                out[row * INF_PITCH + col] = 0.0f;
+            }
+        }
+        if (nbw <= 1) infer_layer16<1>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else if (nbw == 2) infer_layer16<2>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else if (nbw <= 4) infer_layer16<4>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else infer_layer16<8>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        __syncthreads();
+        float* t = in; in = out; out = t;
+    }
+}
+
 extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
                              const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                              float* const* out_d, imx_stream_t stream) {
@@ -865,13 +1009,27 @@ extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets
         n.out = out_d[k];
         IMX_REQUIRE(n.out, "imx_mlp_infer: null output (network %d)", k);
     }
-    const size_t lds = 2ull * INF_ROWS * INF_PITCH * sizeof(float);
+    if (g_num_cu == 0) (void)dw_plan(64, 32, 32);  // fills g_num_cu
+    // 16-sample tiles double the weight traffic out of L2 (every workgroup reads every weight; measured ceiling ~6 TB/s for
+    // these 16-byte-per-lane row gathers: at 4096 envs both variants sit on it, and a deeper, three-set prefetch ring changed
+    // nothing), so they only pay when 32-sample tiles would leave at least half of the CUs without a workgroup
+    const bool small = (int64_t)a.tiles * nnets * 2 <= g_num_cu;
     static bool attr_set = false;
     if (!attr_set) {
-        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2ull * INF_ROWS * INF_PITCH * sizeof(float))));
+        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2ull * INF16_ROWS * INF_PITCH * sizeof(float))));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_infer, dim3((unsigned)(a.tiles * nnets)), dim3(256), lds, (hipStream_t)stream, a);
+    if (small) {
+        a.tiles = (int)((M + INF16_ROWS - 1) / INF16_ROWS);
+        hipLaunchKernelGGL(k_mlp_infer16, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF16_ROWS * INF_PITCH * sizeof(float),
+                           (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(k_mlp_infer, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF_ROWS * INF_PITCH * sizeof(float),
+                           (hipStream_t)stream, a);
+    }
     IMX_HIP(hipGetLastError());
     return 0;
 }

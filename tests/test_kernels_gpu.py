@@ -235,7 +235,8 @@ def test_mlp_dw_elu_fuses_the_activation_backward(libimx, M, N, K):
                                  db1.data_ptr(), scratch.data_ptr(), nbytes, st) != 0  # in-place is refused
 
 
-@pytest.mark.parametrize("M,D,hidden,A", [(4096, 235, (512, 256, 128), 12), (100, 48, (128, 128, 128), 12), (33, 310, (512, 256, 128), 37),
+@pytest.mark.parametrize("M,D,hidden,A", [(4096, 235, (512, 256, 128), 12), (2048, 235, (512, 256, 128), 12),  # 32- and 16-sample tiles
+                                          (100, 48, (128, 128, 128), 12), (33, 310, (512, 256, 128), 37),
                                           (5, 4, (32,), 1), (70, 37, (64, 32), 5)])
 def test_mlp_infer_matches_torch(libimx, M, D, hidden, A):
     """imx_mlp_infer (both networks, all layers, one launch) against the nn.Sequential stacks in fp64."""

@@ -16,7 +16,7 @@ def timeit(fn, n=100):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for M, D in ((4096, 235), (4096, 48), (16384, 235)):
+for M, D in ((4096, 235), (2048, 235), (1024, 235), (16384, 235)):
     pol = ActorCritic(D, D, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128]).cuda()
     x = torch.randn(M, D, device="cuda")
     la, lc = _mlp_layers(pol.actor), _mlp_layers(pol.critic)
