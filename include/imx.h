@@ -337,6 +337,15 @@ int imx_articulation_update(int64_t N, int64_t J, const float* root_transforms_x
                             float* root_lin_vel_w_d, float* root_ang_vel_w_d, float* previous_joint_vel_d,
                             float* joint_acc_d, imx_stream_t stream);
 
+/* IdealPDActuator / ImplicitActuator (dc_motor = 0) and DCMotor (dc_motor = 1) .compute (actuators/actuator_pd.py:115-145,
+ * 184-199, 264-286): computed = kp (q_des - q) + kd (qd_des - qd) + ff, applied = computed clipped to +-effort_limit or, for
+ * the DC motor, to the velocity-dependent window built from saturation_effort and velocity_limit.  All arrays (N,J);
+ * joint_vel_target_d / effort_ff_d may be NULL (zeros).  SURVEY 8f row 4. */
+int imx_actuator_pd(int64_t N, int64_t J, int dc_motor, float saturation_effort, const float* joint_pos_target_d,
+                    const float* joint_vel_target_d, const float* effort_ff_d, const float* joint_pos_d, const float* joint_vel_d,
+                    const float* stiffness_d, const float* damping_d, const float* effort_limit_d, const float* velocity_limit_d,
+                    float* computed_effort_d, float* applied_effort_d, imx_stream_t stream);
+
 /* rsl_rl EmpiricalNormalization.forward (3rd party v2.3.1, absent): if update != 0 fold the batch (N,D) into the running
  * mean / variance (count, mean, var, std are device buffers; Chan's update with the biased batch variance), then
  * out = (x - mean) / (std + eps).  PARITY UNPINNED.  SURVEY 8f row 3. */

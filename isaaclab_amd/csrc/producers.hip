@@ -311,3 +311,45 @@ extern "C" int imx_empirical_normalization(int64_t N, int64_t D, const float* x_
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- explicit actuator models
+// IdealPDActuator.compute (isaaclab/isaaclab/actuators/actuator_pd.py:184-199; ImplicitActuator.compute :115-145 evaluates the
+// same law for reporting): computed = kp*(q_des - q) + kd*(qd_des - qd) + ff; applied = clip(computed, +-effort_limit)
+// (actuator_base.py:309-318).  DCMotor (:264-286): the clip window depends on the joint velocity,
+// max = clip(sat*(1 - qd/v_lim), 0, limit), min = clip(sat*(-1 - qd/v_lim), -limit, 0).  SURVEY 8f row 4.
+__global__ void __launch_bounds__(256)
+k_actuator_pd(int64_t n, int dc_motor, float saturation, const float* __restrict__ q_des, const float* __restrict__ qd_des,
+              const float* __restrict__ ff, const float* __restrict__ q, const float* __restrict__ qd,
+              const float* __restrict__ kp, const float* __restrict__ kd, const float* __restrict__ elim,
+              const float* __restrict__ vlim, float* __restrict__ computed, float* __restrict__ applied) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = qd[i];
+        const float err_p = q_des[i] - q[i];
+        const float err_v = (qd_des ? qd_des[i] : 0.0f) - v;
+        const float c = kp[i] * err_p + kd[i] * err_v + (ff ? ff[i] : 0.0f);
+        const float lim = elim[i];
+        float lo = -lim, hi = lim;
+        if (dc_motor) {
+            const float r = v / vlim[i];
+            hi = fminf(fmaxf(saturation * (1.0f - r), 0.0f), lim);   // torch.clip(x, min=a, max=b) = min(max(x, a), b)
+            lo = fminf(fmaxf(saturation * (-1.0f - r), -lim), 0.0f);
+        }
+        computed[i] = c;
+        applied[i] = fminf(fmaxf(c, lo), hi);
+    }
+}
+
+extern "C" int imx_actuator_pd(int64_t N, int64_t J, int dc_motor, float saturation_effort, const float* joint_pos_target_d,
+                               const float* joint_vel_target_d, const float* effort_ff_d, const float* joint_pos_d,
+                               const float* joint_vel_d, const float* stiffness_d, const float* damping_d, const float* effort_limit_d,
+                               const float* velocity_limit_d, float* computed_effort_d, float* applied_effort_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && J > 0 && joint_pos_target_d && joint_pos_d && joint_vel_d && stiffness_d && damping_d && effort_limit_d &&
+                    computed_effort_d && applied_effort_d, "imx_actuator_pd: bad arguments");
+    IMX_REQUIRE(!dc_motor || velocity_limit_d, "imx_actuator_pd: the DC motor model needs the velocity limits");
+    const int64_t n = N * J;
+    hipLaunchKernelGGL(k_actuator_pd, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, n,
+                       dc_motor, saturation_effort, joint_pos_target_d, joint_vel_target_d, effort_ff_d, joint_pos_d, joint_vel_d,
+                       stiffness_d, damping_d, effort_limit_d, velocity_limit_d, computed_effort_d, applied_effort_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

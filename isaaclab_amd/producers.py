@@ -158,3 +158,27 @@ class ArticulationRootState:
             self.root_ang_vel_w.data_ptr(), self._previous_joint_vel.data_ptr(), self.joint_acc.data_ptr(),
             _lib.current_stream(self.device)))
         self.joint_vel = dof_velocities
+
+
+class PDActuator:
+    """``IdealPDActuator`` / ``ImplicitActuator`` (reporting) / ``DCMotor`` ``.compute`` on libimx
+    (reference isaaclab/actuators/actuator_pd.py:115-145,184-199,264-286): ``computed_effort`` and ``applied_effort`` (N,J)."""
+
+    def __init__(self, stiffness, damping, effort_limit, velocity_limit=None, saturation_effort: float | None = None):
+        self.stiffness, self.damping, self.effort_limit = stiffness.contiguous(), damping.contiguous(), effort_limit.contiguous()
+        self.velocity_limit = None if velocity_limit is None else velocity_limit.contiguous()
+        self.saturation_effort = saturation_effort
+        if stiffness.device.type != "cuda":
+            raise RuntimeError("PDActuator needs a GPU: libimx has no CPU path")
+        self.computed_effort = torch.zeros_like(self.stiffness)
+        self.applied_effort = torch.zeros_like(self.stiffness)
+
+    def compute(self, joint_pos_target, joint_pos, joint_vel, joint_vel_target=None, effort_ff=None):
+        N, J = self.stiffness.shape
+        p = _lib.ptr
+        dc = self.saturation_effort is not None
+        check(lib().imx_actuator_pd(N, J, int(dc), float(self.saturation_effort or 0.0), p(joint_pos_target), p(joint_vel_target),
+                                    p(effort_ff), p(joint_pos), p(joint_vel), p(self.stiffness), p(self.damping), p(self.effort_limit),
+                                    p(self.velocity_limit), p(self.computed_effort), p(self.applied_effort),
+                                    _lib.current_stream(self.stiffness.device)))
+        return self.applied_effort

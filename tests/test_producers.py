@@ -293,3 +293,36 @@ def test_terrain_curriculum_hip_matches_reference():
     pos[:, 0] += 5.0  # walked 5 m > half a tile: everyone moves up from the last level
     cur2.update(None, pos, c("curr/command"))
     assert int(levels2.min()) >= 0 and int(levels2.max()) < meta["R"] and len(torch.unique(levels2)) > 3
+
+
+# ------------------------------------------------------------------------------------------------ actuators (8f row 4)
+def _act_golden():
+    return np.load(os.path.join(GOLDEN, "actuators.npz"))
+
+
+def test_actuator_oracle_matches_reference():
+    from oracle.producers_oracle import actuator_pd
+
+    z = _act_golden()
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    sat = json.loads(str(z["meta"]))["saturation_effort"]
+    for tag, kw in (("ideal", {}), ("dc", dict(velocity_limit=t("velocity_limit"), saturation_effort=sat))):
+        c, a = actuator_pd(t(f"{tag}/q_des"), t(f"{tag}/qd_des"), t(f"{tag}/ff"), t(f"{tag}/q"), t(f"{tag}/qd"), t("stiffness"), t("damping"),
+                           t("effort_limit"), **kw)
+        assert_close(c, t(f"{tag}/computed"), 1e-6, f"{tag} computed")
+        assert_close(a, t(f"{tag}/applied"), 1e-6, f"{tag} applied")
+
+
+@pytest.mark.gpu
+def test_actuator_hip_matches_reference():
+    from isaaclab_amd.producers import PDActuator
+
+    z = _act_golden()
+    c = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    sat = json.loads(str(z["meta"]))["saturation_effort"]
+    for tag, kw in (("ideal", {}), ("dc", dict(velocity_limit=c("velocity_limit"), saturation_effort=sat))):
+        act = PDActuator(c("stiffness"), c("damping"), c("effort_limit"), **kw)
+        applied = act.compute(c(f"{tag}/q_des"), c(f"{tag}/q"), c(f"{tag}/qd"), c(f"{tag}/qd_des"), c(f"{tag}/ff"))
+        assert_close(act.computed_effort, c(f"{tag}/computed"), 1e-5, f"{tag} computed")
+        assert_close(applied, c(f"{tag}/applied"), 1e-5, f"{tag} applied")
+        assert float((applied != act.computed_effort).float().mean()) > 0.05  # the limits are exercised
