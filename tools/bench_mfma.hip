@@ -3,7 +3,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LD 160
-// MODE 0: MFMAs only (register operands); 1: + LDS ping-pong reads; 2: + one barrier per stage; 3: like 2 with 4 extra idle waves at the barrier
+// MODE 0: MFMAs only (register operands); 1: + LDS ping-pong reads; 2: + one barrier per stage; 4: b128 reads from a [row][k] layout (pitch 36 floats), four k-steps per float4, + barrier
 template <int MODE>
 __global__ void __launch_bounds__(512) k(int nst, float* out) {
     __shared__ float sY[2][32 * LD];
@@ -18,6 +18,26 @@ __global__ void __launch_bounds__(512) k(int nst, float* out) {
     const int lane = t & 63, w = t >> 6, r = lane & 31, half = lane >> 5, wn = w & 1, wk = w >> 1;
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+    if (MODE == 4) {
+        const float* base = &sY[0][0];
+        for (int st = 0; st < nst; ++st) {
+            const float* pa = base + (st & 1) * 4608 + (wn * 64 + r) * 36 + 4 * half;       // [128 rows][36]
+            const float* pb = base + 9216 + (st & 1) * 4608 + (wk * 64 + r) * 36 + 4 * half;
+            float4 A0 = *(const float4*)pa, A1 = *(const float4*)(pa + 32 * 36), B0 = *(const float4*)pb, B1 = *(const float4*)(pb + 32 * 36);
+            float4 An0 = A0, An1 = A1, Bn0 = B0, Bn1 = B1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) { An0 = *(const float4*)(pa + 8 * (g + 1)); An1 = *(const float4*)(pa + 32 * 36 + 8 * (g + 1)); Bn0 = *(const float4*)(pb + 8 * (g + 1)); Bn1 = *(const float4*)(pb + 32 * 36 + 8 * (g + 1)); }
+                __builtin_amdgcn_sched_barrier(0);
+#define STEP(c) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc[0][0], 0, 0, 0); acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc[0][1], 0, 0, 0); acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc[1][0], 0, 0, 0); acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc[1][1], 0, 0, 0);
+                STEP(x) STEP(y) STEP(z) STEP(w)
+#undef STEP
+                __builtin_amdgcn_sched_barrier(0);
+                A0 = An0; A1 = An1; B0 = Bn0; B1 = Bn1;
+            }
+            __syncthreads();
+        }
+    } else
     for (int st = 0; st < nst; ++st) {
         const float* py = sY[st & 1] + half * LD + wn * 64 + r;
         const float* px = sX[st & 1] + half * LD + wk * 64 + r;
@@ -64,6 +84,7 @@ int main() {
         run<1>(256, 256, nst, out, "+ LDS ping-pong reads");
         run<2>(256, 256, nst, out, "+ barrier/stage (4 waves)");
         run<2>(256, 512, nst, out, "+ barrier/stage (4 mult + 4 idle waves)");
+        run<4>(256, 512, nst, out, "b128 [row][k] pitch-36 reads + barrier (4 mult + 4 idle)");
         run<0>(512, 256, nst, out, "MFMA only, 2 WG/CU");
         run<1>(512, 256, nst, out, "+ LDS reads, 2 WG/CU");
     }
