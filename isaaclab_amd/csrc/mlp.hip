@@ -240,15 +240,21 @@ __global__ void __launch_bounds__(512, 1) k_mlp_dw(DwArgs a) {
     }
     // partial tile of this split (rows = out-features on the accumulator registers, columns = in-features on the lanes)
     float* part = a.part + (size_t)s * a.N * a.K;
+    const bool interior = n0 + DW_T <= a.N && k0 + DW_T <= a.K;  // unconditional stores: no wait between them
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) {
             const int k = k0 + wk * 64 + bj * 32 + r;
+            if (interior) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = n0 + wn * 64 + bi * 32 + acc_row(q, half);
-                if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = acc[bi][bj][q];
+                for (int q = 0; q < 16; ++q) part[(size_t)(n0 + wn * 64 + bi * 32 + acc_row(q, half)) * a.K + k] = acc[bi][bj][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int n = n0 + wn * 64 + bi * 32 + acc_row(q, half);
+                    if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = acc[bi][bj][q];
+                }
             }
         }
     __syncthreads();  // pairs with the movers' barrier before their bias-gradient sum
@@ -445,12 +451,18 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
                 const float av = (row < M && o < A) ? dY[row * A + o] : 0.0f;
                 dx = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[s], dx, 0, 0, 0);
             }
+        if (m0 + 32 <= M) {  // interior block: unconditional stores
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int64_t row = m0 + acc_row(q, half);
-            if (row < M) {
-                const float g = has_act ? (hv[q] > 0.0f ? 1.0f : hv[q] + alpha) : 1.0f;  // ELU' from the saved output
-                dprev[row * (int64_t)K + kc] = dx[q] * g;
+            for (int q = 0; q < 16; ++q) {
+                const float g = (has_act && hv[q] <= 0.0f) ? hv[q] + alpha : 1.0f;  // ELU' from the saved output
+                dprev[(m0 + acc_row(q, half)) * (int64_t)K + kc] = dx[q] * g;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t row = m0 + acc_row(q, half);
+                const float g = (has_act && hv[q] <= 0.0f) ? hv[q] + alpha : 1.0f;
+                if (row < M) dprev[row * (int64_t)K + kc] = dx[q] * g;
             }
         }
 #pragma unroll
@@ -754,19 +766,32 @@ __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K
         mult(Qa, Qb);
     }
     if (g < ng) mult(Pa, Pb);  // odd number of groups: P holds the last one
-    // epilogue: accumulator rows = samples (registers), columns = out-features (lanes)
+    // epilogue: accumulator rows = samples (registers), columns = out-features (lanes).  Branch-free arithmetic (ELU as a
+    // select over an unconditionally evaluated exp) and unconditional LDS stores: a store inside a divergent branch makes
+    // the compiler wait for the previous one.  Columns beyond N of a hidden layer land in the zero-padding region, which
+    // is re-zeroed by the caller before the next layer reads it -- only the last layer (global stores) is guarded.
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const int n = (w + 4 * j) * 32 + r;
-        if (n >= N) continue;
-        const float bv = bias[n];
+        const float bv = bias[n < N ? n : N - 1];
+        float v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = acc_row(q, half);
-            float v = acc[j][q] + bv;
-            if (elu) v = v > 0.0f ? v : (expf(v) - 1.0f) * alpha;
-            if (sOut) sOut[row * INF_PITCH + n] = v;
-            else if (m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v;
+            float x = acc[j][q] + bv;
+            const float e = (expf(fminf(x, 0.0f)) - 1.0f) * alpha;
+            v[q] = (elu && x <= 0.0f) ? e : x;
+        }
+        if (sOut) {
+            if (n < INF_MAXD) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sOut[acc_row(q, half) * INF_PITCH + n] = n < N ? v[q] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = acc_row(q, half);
+                if (n < N && m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v[q];
+            }
         }
     }
 }
