@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
     for (int k = 4 * q; k < K; k += 16) {  // the 4 lanes of a sample read one 64-byte run per trip
         float4 hv = *reinterpret_cast<const float4*>(hr + k);
         if (ELU_IN) {
-            hv.x = hv.x > 0.0f ? hv.x : (expf(hv.x) - 1.0f) * alpha;
-            hv.y = hv.y > 0.0f ? hv.y : (expf(hv.y) - 1.0f) * alpha;
-            hv.z = hv.z > 0.0f ? hv.z : (expf(hv.z) - 1.0f) * alpha;
-            hv.w = hv.w > 0.0f ? hv.w : (expf(hv.w) - 1.0f) * alpha;
+            // branch-free: exp evaluated unconditionally (on min(x, 0)), result chosen by a select
+            const float ex = (expf(fminf(hv.x, 0.0f)) - 1.0f) * alpha, ey = (expf(fminf(hv.y, 0.0f)) - 1.0f) * alpha;
+            const float ez = (expf(fminf(hv.z, 0.0f)) - 1.0f) * alpha, ew = (expf(fminf(hv.w, 0.0f)) - 1.0f) * alpha;
+            hv.x = hv.x > 0.0f ? hv.x : ex; hv.y = hv.y > 0.0f ? hv.y : ey; hv.z = hv.z > 0.0f ? hv.z : ez; hv.w = hv.w > 0.0f ? hv.w : ew;
             if (live) *reinterpret_cast<float4*>(hr + k) = hv;
         }
 #pragma unroll
@@ -396,14 +396,20 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
                 acc[o] = fmaf(hv.w, wv.w, fmaf(hv.z, wv.z, fmaf(hv.y, wv.y, fmaf(hv.x, wv.x, acc[o]))));
             }
     }
+    // reduce over the 4 lanes of a sample first, then ONE guarded region with all the stores back to back (a store inside its
+    // own divergent branch would wait for the previous one: 9 us instead of 4 for 12 outputs)
 #pragma unroll
-    for (int o = 0; o < AMAX; ++o)
-        if (o < A) {
-            float v = acc[o];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            if (q == 0 && live) y[row * A + o] = v + b[o];
-        }
+    for (int o = 0; o < AMAX; ++o) {
+        float v = acc[o];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        acc[o] = v + b[o < A ? o : 0];
+    }
+    if (q == 0 && live) {
+#pragma unroll
+        for (int o = 0; o < AMAX; ++o)
+            if (o < A) y[row * A + o] = acc[o];  // uniform condition
+    }
 }
 
 // One wave per 32 in-features.  Per block of 32 samples: dX = dY W on the matrix core (A <= 32 reduction steps of 2), the
@@ -928,19 +934,29 @@ __device__ __forceinline__ void infer_layer16(const float* __restrict__ sIn, int
         mult(Qa, Qb);
     }
     if (g < ng) mult(Pa, Pb);
-    // epilogue: 16x16 accumulator: column = lane & 15, row = (lane >> 4) * 4 + register
+    // epilogue: 16x16 accumulator: column = lane & 15, row = (lane >> 4) * 4 + register (branch-free, as in infer_layer)
 #pragma unroll
     for (int b = 0; b < NBW; ++b) {
         const int n = (w + 4 * b) * 16 + j;
-        if (n >= N) continue;
-        const float bv = bias[n];
+        const float bv = bias[n < N ? n : N - 1];
+        float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int row = kq * 4 + q;
-            float v = acc[b][q] + bv;
-            if (elu) v = v > 0.0f ? v : (expf(v) - 1.0f) * alpha;
-            if (sOut) sOut[row * INF_PITCH + n] = v;
-            else if (m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v;
+            const float x = acc[b][q] + bv;
+            const float e = (expf(fminf(x, 0.0f)) - 1.0f) * alpha;
+            v[q] = (elu && x <= 0.0f) ? e : x;
+        }
+        if (sOut) {
+            if (n < INF_MAXD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sOut[(kq * 4 + q) * INF_PITCH + n] = n < N ? v[q] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = kq * 4 + q;
+                if (n < N && m0 + row < M) gOut[(m0 + row) * (int64_t)N + n] = v[q];
+            }
         }
     }
 }
