@@ -38,7 +38,8 @@ enum imx_header_word {
     IMX_H_ACT_OFF, IMX_H_TOTAL_WORDS, IMX_H_NB /* articulation bodies */, IMX_H_GRAV_X /*f32*/, IMX_H_GRAV_Y,
     IMX_H_GRAV_Z, IMX_H_NREW_ALL /* reward terms incl. zero-weight */, IMX_H_RAY_OFF /* R*3 f32 local ray starts */,
     IMX_H_RAYDIR_X /*f32*/, IMX_H_RAYDIR_Y, IMX_H_RAYDIR_Z, IMX_H_RAY_MAXDIST /*f32*/, IMX_H_MAX_EP_LEN_S /*f32*/,
-    IMX_H_NEXT_REW, IMX_H_NEXT_TERM, IMX_H_NEXT_OBS, IMX_H_RAY_YAW_ONLY, IMX_H_CMD_DIM
+    IMX_H_NEXT_REW, IMX_H_NEXT_TERM, IMX_H_NEXT_OBS, IMX_H_RAY_YAW_ONLY, IMX_H_CMD_DIM,
+    IMX_H_MOD_STATE /* floats of observation-modifier state per env (imx_buffers.mod_state row width) */
 };
 
 /* record layout (IMX_REC_WORDS int32/f32 words) */
@@ -55,6 +56,19 @@ enum imx_rec_word {
 #define IMX_F_CLIP 8
 #define IMX_F_SCALE 16
 #define IMX_F_QUAT_UNIQUE 32
+/* the obs record carries a modifier program (ObservationTermCfg.modifiers, observation_manager.py:310-312), run on the raw
+ * term value before noise/clip/scale: IMX_R_IDS2_OFF = word offset of the program, IMX_R_NIDS2 = its length in words,
+ * IMX_R_P1 (int) = first float of the term's state in a mod_state row.  Program = ops back to back, 4 words each
+ * [op, a, b, soff] (DIGITAL_FILTER: [op, na, nb, soff] followed by na + nb f32 coefficients A then B).  State of element
+ * j of a term of width d: mod_state[e][P1 + (soff + k) * d + j]; zeroed for envs reset this step before it is used. */
+#define IMX_F_MODIFIERS 64
+enum imx_mod_op {            /* utils/modifiers/modifier.py */
+    IMX_M_SCALE = 1,         /* :22-32   a = multiplier */
+    IMX_M_BIAS,              /* :49-60   a = value */
+    IMX_M_CLIP,              /* :35-46   a = lo (-inf if None), b = hi (+inf if None) */
+    IMX_M_INTEGRATOR,        /* :179-259 a = dt; state: integral, y_prev */
+    IMX_M_DIGITAL_FILTER     /* :63-176  state: x_n[nb], y_n[na] */
+};
 /* action record flags */
 #define IMX_F_ACT_DEFAULT_POS_OFFSET 1 /* JointPositionAction use_default_offset (joint_actions.py:152-154) */
 #define IMX_F_ACT_DEFAULT_VEL_OFFSET 2 /* JointVelocityAction (joint_actions.py:206-208) */
@@ -175,6 +189,7 @@ typedef struct imx_buffers {
     float* log_out;              /* (NREW_ALL + NTERM + 1) Episode_Reward/<term>, Episode_Termination/<term>, count */
     float* obs;                  /* (N,D) managers/observation_manager.py:238-335 */
     void* scratch;               /* imx_plan_scratch_bytes(plan, N) bytes */
+    float* mod_state;            /* (N, IMX_H_MOD_STATE) DigitalFilter / Integrator state; NULL when the plan has none */
 } imx_buffers_t;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */

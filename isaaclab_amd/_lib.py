@@ -19,7 +19,7 @@ STATE_FIELDS = (
 )
 BUFFER_FIELDS = (
     "episode_length_buf", "action", "prev_action", "processed_action", "reward_buf", "episode_sums", "step_reward",
-    "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch",
+    "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch", "mod_state",
 )
 
 

@@ -59,6 +59,7 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
     auto& w = p->host;
     p->J = w[IMX_H_J]; p->B = w[IMX_H_B]; p->H = w[IMX_H_H]; p->A = w[IMX_H_A]; p->D = w[IMX_H_D];
     p->R = w[IMX_H_R]; p->NB = w[IMX_H_NB]; p->CMD = w[IMX_H_CMD_DIM];
+    IMX_REQUIRE(w[IMX_H_MOD_STATE] >= 0 && w[IMX_H_MOD_STATE] < (1 << 20), "plan: modifier state width %d", w[IMX_H_MOD_STATE]);
     p->nterm = w[IMX_H_NTERM]; p->nrew = w[IMX_H_NREW]; p->nobs = w[IMX_H_NOBS]; p->nact = w[IMX_H_NACT];
     p->nrew_all = w[IMX_H_NREW_ALL];
     p->term_off = w[IMX_H_TERM_OFF]; p->rew_off = w[IMX_H_REW_OFF]; p->obs_off = w[IMX_H_OBS_OFF];
@@ -142,6 +143,32 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
         if (op == IMX_O_GENERATED_COMMANDS) IMX_REQUIRE(d == p->CMD, "plan: command dim mismatch");
         if (op == IMX_O_EXTERNAL)
             IMX_REQUIRE(r[IMX_R_AUX0] >= 0 && r[IMX_R_AUX0] + d <= w[IMX_H_NEXT_OBS], "plan: ext_obs columns out of range");
+        if (r[IMX_R_FLAGS] & IMX_F_MODIFIERS) {  // modifier program: bounds, op codes, state slots inside the row
+            const int po = r[IMX_R_IDS2_OFF], pn = r[IMX_R_NIDS2], so = r[IMX_R_P1];
+            IMX_REQUIRE(op != IMX_O_EXTERNAL, "plan: observation %d: modifiers on a Python-evaluated term", k);
+            IMX_REQUIRE(po >= IMX_HEADER_WORDS && pn > 0 && (size_t)po + pn <= nwords, "plan: observation %d: modifier program out of range", k);
+            int slots = 0;
+            for (int q = 0; q < pn;) {
+                IMX_REQUIRE(q + 4 <= pn, "plan: observation %d: truncated modifier program", k);
+                const int mop = w[po + q];
+                IMX_REQUIRE(mop >= IMX_M_SCALE && mop <= IMX_M_DIGITAL_FILTER, "plan: observation %d: unknown modifier op %d", k, mop);
+                int need = 0, len = 4;
+                if (mop == IMX_M_INTEGRATOR) need = 2;
+                if (mop == IMX_M_DIGITAL_FILTER) {
+                    const int na = w[po + q + 1], nb = w[po + q + 2];
+                    IMX_REQUIRE(na >= 1 && nb >= 1 && na <= 64 && nb <= 64, "plan: observation %d: filter orders %d/%d", k, na, nb);
+                    need = na + nb; len = 4 + na + nb;
+                    IMX_REQUIRE(q + len <= pn, "plan: observation %d: truncated filter coefficients", k);
+                }
+                if (need) {
+                    IMX_REQUIRE(w[po + q + 3] == slots, "plan: observation %d: modifier state slots must be consecutive", k);
+                    slots += need;
+                }
+                q += len;
+            }
+            const int MSw = w[IMX_H_MOD_STATE];
+            IMX_REQUIRE(so >= 0 && so + slots * d <= MSw, "plan: observation %d: modifier state [%d, %d) outside the %d-float row", k, so, so + slots * d, MSw);
+        }
         static const int fixed_dim[] = {0, 1, 3, 3, 3, 3, 4, 3, 3};
         if (op <= IMX_O_ROOT_ANG_VEL_W) IMX_REQUIRE(d == fixed_dim[op], "plan: observation op %d must have dim %d", op, fixed_dim[op]);
         for (int h = 0; h < hist; ++h)
@@ -217,6 +244,17 @@ extern "C" int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** 
         x[15] = w[ro + IMX_R_DIM];                                                        // slot stride (term width)
         w.insert(w.end(), x, x + 16);
     }
+    p->xmod_off = (int)w.size();
+    p->MS = w[IMX_H_MOD_STATE];
+    for (int i = 0; i < p->DC; ++i) {
+        const int c = order[i], k = col[c] >> 16, j = col[c] & 0xFFFF;
+        const size_t ro = (size_t)p->obs_off + (size_t)k * IMX_REC_WORDS;
+        int32_t x[4] = {0, 0, 0, 0};
+        if (w[ro + IMX_R_FLAGS] & IMX_F_MODIFIERS) {
+            x[0] = w[ro + IMX_R_IDS2_OFF]; x[1] = w[ro + IMX_R_NIDS2]; x[2] = w[ro + IMX_R_P1] + j; x[3] = w[ro + IMX_R_DIM];
+        }
+        w.insert(w.end(), x, x + 4);
+    }
     if (imx_device_count() > 0) {
         IMX_HIP(hipMalloc((void**)&p->dev, w.size() * sizeof(int32_t)));
         IMX_HIP(hipMemcpy(p->dev, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -241,7 +279,7 @@ PlanView imx_plan_view(const imx_plan* p) {
     v.nterm = p->nterm; v.nrew = p->nrew; v.nobs = p->nobs; v.nact = p->nact; v.nrew_all = p->nrew_all;
     v.term_off = p->term_off; v.rew_off = p->rew_off; v.obs_off = p->obs_off; v.act_off = p->act_off;
     v.ray_off = p->ray_off; v.col_off = p->col_off; v.order_off = p->order_off; v.n_ray_cols = p->n_ray_cols;
-    v.skip_off = p->skip_off; v.nskip = p->nskip; v.xcol_off = p->xcol_off; v.DC = p->DC;
+    v.skip_off = p->skip_off; v.nskip = p->nskip; v.xcol_off = p->xcol_off; v.DC = p->DC; v.xmod_off = p->xmod_off; v.MS = p->MS;
     v.max_ep_len = w[IMX_H_MAX_EP_LEN];
     v.step_dt = wf(w[IMX_H_STEP_DT]);
     v.max_ep_len_s = wf(w[IMX_H_MAX_EP_LEN_S]);

@@ -43,6 +43,8 @@ struct imx_plan {
     int skip_off = 0, nskip = 0;  // reward slots with no record (zero weight)
     int xcol_off = 0;             // DC x 16 words: per-column expansion of the obs records, ray columns first
     int DC = 0;                   // computed observation columns (= D unless a term keeps a history window)
+    int xmod_off = 0;             // DC x 4 words: [program offset, program words, state offset of this column, term width]
+    int MS = 0;                   // floats of modifier state per env
     bool needs_mesh = false;
 };
 
@@ -51,7 +53,7 @@ struct PlanView {
     const int32_t* w;  // device blob
     int J, B, H, A, D, R, NB, CMD;
     int nterm, nrew, nobs, nact, nrew_all;
-    int term_off, rew_off, obs_off, act_off, ray_off, col_off, order_off, n_ray_cols, skip_off, nskip, xcol_off, DC;
+    int term_off, rew_off, obs_off, act_off, ray_off, col_off, order_off, n_ray_cols, skip_off, nskip, xcol_off, DC, xmod_off, MS;
     int max_ep_len;
     float step_dt, max_ep_len_s;
     float gx, gy, gz;

@@ -503,6 +503,59 @@ IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restr
     return v;
 }
 
+// ObservationTermCfg.modifiers (observation_manager.py:310-312; utils/modifiers/modifier.py): the term's modifier program,
+// run on the raw value of ONE element; filter / integrator state of that element lives in the env's mod_state row at
+// st[(soff + k) * d] (element-minor, so the lanes of a term touch consecutive floats).  `zero`: the env was reset this step
+// (ObservationManager.reset zeroes the state before the next compute) -- old state is ignored, new state is written.
+IMX_DEV float apply_modifiers(const int32_t* __restrict__ W, int xmod, float v, float* __restrict__ row, bool zero) {
+    const int4 m = *reinterpret_cast<const int4*>(W + xmod);
+    const int po = m.x, pn = m.y, d = m.w;
+    float* st = row + m.z;
+    for (int q = 0; q < pn; q += 4) {
+        const int op = W[po + q];
+        const float a = f_of(W[po + q + 1]), b = f_of(W[po + q + 2]);
+        const int soff = W[po + q + 3];
+        switch (op) {
+            case IMX_M_SCALE: v = v * a; break;
+            case IMX_M_BIAS: v = v + a; break;
+            case IMX_M_CLIP: v = fminf(fmaxf(v, a), b); break;
+            case IMX_M_INTEGRATOR: {  // integral += (data + y_prev) / 2 * dt; y_prev = data (modifier.py:247-259)
+                float* s = st + soff * d;
+                const float yp = zero ? 0.0f : s[d];
+                const float integ = (zero ? 0.0f : s[0]) + (v + yp) / 2.0f * a;
+                s[0] = integ; s[d] = v;
+                v = integ;
+            } break;
+            case IMX_M_DIGITAL_FILTER: {  // y = x_n . B - y_n . A with both windows rolled by one (modifier.py:160-176)
+                const int na = W[po + q + 1], nb = W[po + q + 2];
+                float* xs = st + soff * d;
+                float* ys = xs + nb * d;
+                const int32_t* A = W + po + q + 4;
+                const int32_t* B = A + na;
+                float accx = 0.0f, accy = 0.0f, carry = v;
+                for (int k = 0; k < nb; ++k) {
+                    const float old = zero ? 0.0f : xs[k * d];
+                    xs[k * d] = carry;
+                    accx += carry * f_of(B[k]);
+                    carry = old;
+                }
+                for (int k = 0; k < na; ++k) accy += (zero ? 0.0f : ys[k * d]) * f_of(A[k]);
+                const float y = accx - accy;
+                carry = y;
+                for (int k = 0; k < na; ++k) {
+                    const float old = zero ? 0.0f : ys[k * d];
+                    ys[k * d] = carry;
+                    carry = old;
+                }
+                v = y;
+                q += na + nb;
+            } break;
+            default: break;
+        }
+    }
+    return v;
+}
+
 // k_frame: one lane per env -- root-frame vectors (ArticulationData.root_lin_vel_b / root_ang_vel_b /
 // projected_gravity_b), sensor position and the yaw-only sensor quaternion (yaw_quat, utils/math.py:521-542), once per
 // env per step instead of once per wave of k_obs (PMC: the transcendental prologue was ~40 % of k_obs's VALU work).
@@ -598,6 +651,8 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
             } break;
             default: break;
         }
+        if (flags & IMX_F_MODIFIERS)
+            v = apply_modifiers(W, P.xmod_off + 4 * i, v, Bf.mod_state + e * P.MS, fill_all || Bf.reset_buf[e]);
         const float vp = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
         float* o = Bf.obs + e * D + c;  // newest slot
         const int hist = x.d.z;
@@ -741,6 +796,8 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w && st->root_pos_w, "root state missing");
     IMX_REQUIRE(!plan->needs_mesh || mesh, "plan has a height_scan term but no mesh was given");
     IMX_REQUIRE(plan->DC == plan->D || bf->reset_buf, "imx_observations: observation history needs the reset mask (reset_buf)");
+    IMX_REQUIRE(plan->MS == 0 || (bf->mod_state && bf->reset_buf),
+                "imx_observations: the plan has stateful observation modifiers: mod_state (N x %d floats) and reset_buf are required", plan->MS);
     const auto& w = plan->host;
     for (int k = 0; k < plan->nobs; ++k) {
         const int op = w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP];

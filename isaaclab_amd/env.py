@@ -447,6 +447,8 @@ class ManagerBasedRLEnv:
         self._plan_h = ctypes.c_void_p()
         check(self._lib.imx_plan_create(blob.ctypes.data, blob.size, ctypes.byref(self._plan_h)))
         self._scratch = torch.zeros(int(self._lib.imx_plan_scratch_bytes(self._plan_h, N)), dtype=torch.uint8, device=dev)
+        # DigitalFilter / Integrator state of observation modifiers (utils/modifiers/modifier.py), zeroed per env on reset by k_obs
+        self._mod_state = torch.zeros(N, plan.mod_state_dim, device=dev) if plan.mod_state_dim > 0 else None
         self._bufs = ImxBuffers(
             episode_length_buf=self._episode_length_buf.data_ptr(), action=self._action.data_ptr(),
             prev_action=self._prev_action.data_ptr(), processed_action=self._processed_action.data_ptr(),
@@ -455,7 +457,7 @@ class ManagerBasedRLEnv:
             terminated=self.reset_terminated.data_ptr(), truncated=self.reset_time_outs.data_ptr(),
             reset_buf=self.reset_buf.data_ptr(), reset_env_ids=self._reset_env_ids.data_ptr(),
             counters=self._counters.data_ptr(), log_out=self._log_out.data_ptr(), obs=self._obs.data_ptr(),
-            scratch=self._scratch.data_ptr())
+            scratch=self._scratch.data_ptr(), mod_state=self._mod_state.data_ptr() if self._mod_state is not None else None)
         self._state_cache: dict[int, ImxState] = {}
         self._root_cache = None
 

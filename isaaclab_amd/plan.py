@@ -29,10 +29,11 @@ REC_WORDS = 20
 H = dict(MAGIC=0, VERSION=1, J=2, B=3, H=4, A=5, D=6, R=7, NTERM=8, NREW=9, NOBS=10, NACT=11, MAX_EP_LEN=12,
          STEP_DT=13, TERM_OFF=14, REW_OFF=15, OBS_OFF=16, ACT_OFF=17, TOTAL_WORDS=18, NB=19, GRAV_X=20, GRAV_Y=21,
          GRAV_Z=22, NREW_ALL=23, RAY_OFF=24, RAYDIR_X=25, RAYDIR_Y=26, RAYDIR_Z=27, RAY_MAXDIST=28, MAX_EP_LEN_S=29,
-         NEXT_REW=30, NEXT_TERM=31, NEXT_OBS=32, RAY_YAW_ONLY=33, CMD_DIM=34)
+         NEXT_REW=30, NEXT_TERM=31, NEXT_OBS=32, RAY_YAW_ONLY=33, CMD_DIM=34, MOD_STATE=35)
 R = dict(OP=0, IDS_OFF=1, NIDS=2, IDS2_OFF=3, NIDS2=4, WEIGHT=5, P0=6, P1=7, P2=8, P3=9, OUT=10, DIM=11, FLAGS=12,
          NOISE_LO=13, NOISE_HI=14, CLIP_LO=15, CLIP_HI=16, SCALE=17, AUX0=18, AUX1=19)
-F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE = 1, 2, 4, 8, 16, 32
+F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE, F_MODIFIERS = 1, 2, 4, 8, 16, 32, 64
+M_OPS = dict(SCALE=1, BIAS=2, CLIP=3, INTEGRATOR=4, DIGITAL_FILTER=5)
 F_ACT_DEFAULT_POS_OFFSET, F_ACT_DEFAULT_VEL_OFFSET, F_ACT_CLIP = 1, 2, 4
 
 T_OPS = dict(TIME_OUT=1, ILLEGAL_CONTACT=2, JOINT_POS_MANUAL_LIMIT=3, BAD_ORIENTATION=4, ROOT_HEIGHT_BELOW_MIN=5,
@@ -128,6 +129,7 @@ class Plan:
     n_ext_rew: int = 0
     n_ext_term: int = 0
     n_ext_obs: int = 0
+    mod_state_dim: int = 0  # floats of observation-modifier state per env (DigitalFilter / Integrator)
     gravity_dir: tuple[float, float, float] = (0.0, 0.0, -1.0)
 
 
@@ -151,6 +153,39 @@ class _Blob:
             assert len(r) == REC_WORDS
             self.w.extend(r)
         return off
+
+
+def compile_modifiers(mods) -> tuple[list[int], int]:
+    """``ObservationTermCfg.modifiers`` (isaaclab/utils/modifiers/modifier_cfg.py; applied at observation_manager.py:310-312)
+    -> (program words, state slots per element) in the format of include/imx.h ``IMX_F_MODIFIERS``.  Raises
+    NotImplementedError for a modifier that is not one of modifier.py's five."""
+    prog: list[int] = []
+    slots = 0
+    for m in mods:
+        m = m if isinstance(m, dict) else m.to_dict()
+        mod, fn = _short(func_name(m["func"]))
+        if not mod.startswith("isaaclab.utils.modifiers"):
+            raise NotImplementedError(f"modifier {mod}:{fn}")
+        p = m.get("params") or {}
+        if fn == "scale":
+            prog += [M_OPS["SCALE"], _f2w(f32(p["multiplier"])), 0, 0]
+        elif fn == "bias":
+            prog += [M_OPS["BIAS"], _f2w(f32(p["value"])), 0, 0]
+        elif fn == "clip":
+            lo, hi = p["bounds"]
+            prog += [M_OPS["CLIP"], _f2w(-math.inf if lo is None else f32(lo)), _f2w(math.inf if hi is None else f32(hi)), 0]
+        elif fn == "Integrator":
+            prog += [M_OPS["INTEGRATOR"], _f2w(f32(m["dt"])), 0, slots]
+            slots += 2
+        elif fn == "DigitalFilter":
+            A_, B_ = m.get("A"), m.get("B")
+            if A_ is None or B_ is None:  # modifier.py:131-132
+                raise ValueError("Digital filter coefficients A and B must not be None. Please provide valid coefficients.")
+            prog += [M_OPS["DIGITAL_FILTER"], len(A_), len(B_), slots] + [_f2w(f32(x)) for x in list(A_) + list(B_)]
+            slots += len(A_) + len(B_)
+        else:
+            raise NotImplementedError(f"modifier {mod}:{fn}")
+    return prog, slots
 
 
 def _rec(**kw) -> list[int]:
@@ -453,6 +488,7 @@ class PlanCompiler:
         obs_dims: list[tuple[int, ...]] = []
         n_ext_obs = 0
         D = 0
+        mod_state = 0  # floats of modifier state per env
         ray_local = None
         scanner = scene.get("height_scanner")
         ray_dir = (0.0, 0.0, -1.0)
@@ -473,7 +509,18 @@ class PlanCompiler:
                 raise NotImplementedError(f"observation term '{name}': un-flattened history is not on the fused path")
             rec = dict(out=D)
             flags = 0
-            known = tcfg.get("modifiers") is None
+            known = True
+            mod_prog, mod_slots = [], 0
+            if tcfg.get("modifiers"):
+                try:
+                    mod_prog, mod_slots = compile_modifiers(tcfg["modifiers"])
+                    last = _short(func_name(tcfg["modifiers"][-1]["func"]))[1]
+                    # the reference's Integrator returns its state tensor itself; a following in-place clip_/mul_ (no noise in
+                    # between) would write into that state -- not reproduced, such a term stays in Python
+                    if last == "Integrator" and not (tcfg.get("noise") and corruption) and (tcfg.get("clip") is not None or tcfg.get("scale") is not None):
+                        known = False
+                except NotImplementedError:
+                    known = False
             fixed = {f"{_MDP}.observations:base_pos_z": ("BASE_POS_Z", 1), f"{_MDP}.observations:base_lin_vel": ("BASE_LIN_VEL", 3),
                      f"{_MDP}.observations:base_ang_vel": ("BASE_ANG_VEL", 3),
                      f"{_MDP}.observations:projected_gravity": ("PROJECTED_GRAVITY", 3),
@@ -544,6 +591,10 @@ class PlanCompiler:
                 n_ext_obs += dim
                 if hist > 0:
                     raise NotImplementedError(f"observation term '{name}': history on a term evaluated in Python is not supported")
+            if known and mod_prog:
+                flags |= F_MODIFIERS
+                rec.update(ids2_off=blob.ints(mod_prog), nids2=len(mod_prog), p1=int(mod_state))
+                mod_state += mod_slots * dim
             width = max(hist, 1) * dim
             rec.update(dim=dim, flags=flags, aux1=hist)
             obs_recs.append(_rec(**rec))
@@ -565,6 +616,7 @@ class PlanCompiler:
             "TOTAL_WORDS": len(w), "NB": B, "NREW_ALL": len(rew_terms), "RAY_OFF": ray_off,
             "NEXT_REW": n_ext_rew, "NEXT_TERM": n_ext_term, "NEXT_OBS": n_ext_obs,
             "RAY_YAW_ONLY": 1 if (scanner and scanner.get("attach_yaw_only")) else 0, "CMD_DIM": 3,
+            "MOD_STATE": mod_state,
         }
         for k, v in hdr.items():
             w[H[k]] = int(v)
@@ -580,7 +632,8 @@ class PlanCompiler:
                     termination_terms=term_terms, obs_terms=obs_terms, obs_term_dims=obs_dims,
                     action_terms=action_terms, enable_corruption=corruption, ray_starts_local=ray_local,
                     ray_direction=ray_dir, ray_max_distance=ray_max, scanner_cfg=scanner, n_ext_rew=n_ext_rew,
-                    n_ext_term=n_ext_term, n_ext_obs=n_ext_obs, gravity_dir=tuple(float(x) for x in gdir))
+                    n_ext_term=n_ext_term, n_ext_obs=n_ext_obs, gravity_dir=tuple(float(x) for x in gdir),
+                    mod_state_dim=mod_state)
 
 
 def compile_plan(env_cfg: Any, robot: RobotSpec) -> Plan:

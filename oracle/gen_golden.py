@@ -455,6 +455,22 @@ def main():
         hist_cfg.observations.policy.history_length = 3
         hist_cfg.observations.policy.flatten_history_dim = True
         run_task("Isaac-Velocity-Flat-Anymal-C-v0-hist3", hist_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=105)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0-mod"):
+        # observation modifiers (ObservationTermCfg.modifiers; utils/modifiers/modifier.py): stateless chain, IIR/FIR filter,
+        # integrator -- on the flat task, 6 steps so that filter/integrator state and its reset are exercised
+        from isaaclab.utils import modifiers as ref_mod
+
+        mod_cfg = AnymalCFlatEnvCfg()
+        pol = mod_cfg.observations.policy
+        pol.base_lin_vel.modifiers = [ref_mod.ModifierCfg(func=ref_mod.scale, params={"multiplier": 2.0}),
+                                      ref_mod.ModifierCfg(func=ref_mod.bias, params={"value": 0.25}),
+                                      ref_mod.ModifierCfg(func=ref_mod.clip, params={"bounds": (-0.8, None)})]
+        pol.base_ang_vel.modifiers = [ref_mod.DigitalFilterCfg(A=[0.0], B=[0.0, 1.0])]  # unit delay
+        pol.joint_pos.modifiers = [ref_mod.IntegratorCfg(dt=0.02), ref_mod.ModifierCfg(func=ref_mod.clip, params={"bounds": (-0.01, 0.015)})]
+        pol.joint_vel.modifiers = [ref_mod.DigitalFilterCfg(A=[-0.5, 0.1], B=[0.3, 0.2, 0.1]),
+                                   ref_mod.ModifierCfg(func=ref_mod.scale, params={"multiplier": 0.5})]
+        pol.actions.modifiers = [ref_mod.DigitalFilterCfg(A=[0.6], B=[0.4])]  # first-order low-pass
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0-mod", mod_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=6, seed=106)
     if want("Isaac-Velocity-Rough-Anymal-C-v0"):
         run_task("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64,
                  steps=3, seed=103, mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))

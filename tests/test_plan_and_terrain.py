@@ -91,6 +91,50 @@ def test_term_compiler_errors_follow_the_reference():
     assert p.blob[planmod.H["NREW"]] == len([t for t in p.reward_terms if t.weight != 0.0])
 
 
+def test_observation_modifiers_compile_to_programs_and_the_library_validates_them():
+    """ObservationTermCfg.modifiers (utils/modifiers/modifier.py): program encoding, state sizing, and plan validation in the
+    C library (loads without a GPU; no compute)."""
+    import copy
+    import ctypes
+
+    import numpy as np
+
+    from isaaclab_amd._lib import check, lib, ImxError
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0-mod")
+    p = planmod.compile_plan(g.fixture["env"], g.robot)
+    # unit delay 3 x (2+1), integrator 12 x 2, IIR 12 x (3+2), low-pass 12 x (1+1)
+    assert p.mod_state_dim == 9 + 24 + 60 + 24 and p.n_ext_obs == 0
+    prog, slots = planmod.compile_modifiers(g.fixture["env"]["observations"]["policy"]["base_lin_vel"]["modifiers"])
+    assert slots == 0 and prog[0::4] == [planmod.M_OPS["SCALE"], planmod.M_OPS["BIAS"], planmod.M_OPS["CLIP"]]
+    assert prog[10] == planmod._f2w(float("inf"))  # clip upper bound None
+    prog, slots = planmod.compile_modifiers(g.fixture["env"]["observations"]["policy"]["joint_vel"]["modifiers"])
+    assert slots == 5 and prog[:4] == [planmod.M_OPS["DIGITAL_FILTER"], 2, 3, 0] and len(prog) == 4 + 5 + 4
+    L = lib()
+
+    def create(blob):
+        blob = np.ascontiguousarray(blob, np.int32)
+        h = ctypes.c_void_p()
+        check(L.imx_plan_create(blob.ctypes.data, blob.size, ctypes.byref(h)))
+        L.imx_plan_destroy(h)
+
+    create(p.blob)
+    bad = p.blob.copy()
+    bad[planmod.H["MOD_STATE"]] -= 1  # last term's state no longer fits the row
+    with pytest.raises(ImxError, match="modifier state"):
+        create(bad)
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["observations"]["policy"]["joint_vel"]["modifiers"][0]["A"] = None
+    with pytest.raises(ValueError, match="coefficients A and B"):
+        planmod.compile_plan(cfg, g.robot)  # modifier.py:131-132
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["observations"]["policy"]["joint_vel"]["modifiers"] = [{"func": "my_pkg.mods:wobble", "params": {}}]
+    with pytest.raises(NotImplementedError, match="_dim"):
+        planmod.compile_plan(cfg, g.robot)  # unknown modifier: the term would have to be evaluated in Python
+    cfg["observations"]["policy"]["joint_vel"]["_dim"] = 12
+    assert planmod.compile_plan(cfg, g.robot).n_ext_obs == 12
+
+
 def test_policy_is_exportable_like_the_reference_exporter(tmp_path):
     """SURVEY 8f row 3, export compatibility: what isaaclab_rl/rsl_rl/exporter.py::_TorchPolicyExporter does with a policy
     (deepcopy of ``policy.actor``, ``policy.is_recurrent``, normalizer in front, torch.jit.script, save / load) works on this
