@@ -361,6 +361,18 @@ int imx_actuator_pd(int64_t N, int64_t J, int dc_motor, float saturation_effort,
                     const float* stiffness_d, const float* damping_d, const float* effort_limit_d, const float* velocity_limit_d,
                     float* computed_effort_d, float* applied_effort_d, imx_stream_t stream);
 
+/* DelayedPDActuator / RemotizedPDActuator .compute (actuators/actuator_pd.py:289-412; DelayBuffer utils/buffers/delay_buffer.py,
+ * CircularBuffer utils/buffers/circular_buffer.py).  ring_d: (max_delay+1, N, 3, J) f32, caller-owned, persistent; `step` = number of
+ * calls so far (host counter, replaces the reference's pointer); reset_step_d[e] = the `step` of env e's first call after its last
+ * reset (the caller sets it, with the new time_lags_d[e] in [min_delay, max_delay], when it resets the env); effort_limit_d NULL =
+ * no box limit; lookup_d (num_lookup,3) = angle / transmission ratio / max torque samples, ascending angles, or NULL. */
+int imx_actuator_delayed_pd(int64_t N, int64_t J, int max_delay, int64_t step, const int32_t* time_lags_d,
+                            const int64_t* reset_step_d, float* ring_d, const float* joint_pos_target_d,
+                            const float* joint_vel_target_d, const float* effort_ff_d, const float* joint_pos_d,
+                            const float* joint_vel_d, const float* stiffness_d, const float* damping_d,
+                            const float* effort_limit_d, const float* lookup_d, int num_lookup, float* computed_effort_d,
+                            float* applied_effort_d, imx_stream_t stream);
+
 /* rsl_rl EmpiricalNormalization.forward (3rd party v2.3.1, absent): if update != 0 fold the batch (N,D) into the running
  * mean / variance (count, mean, var, std are device buffers; Chan's update with the biased batch variance), then
  * out = (x - mean) / (std + eps).  PARITY UNPINNED.  SURVEY 8f row 3. */

@@ -353,3 +353,75 @@ extern "C" int imx_actuator_pd(int64_t N, int64_t J, int dc_motor, float saturat
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// DelayedPDActuator / RemotizedPDActuator (actuators/actuator_pd.py:289-412).  The three DelayBuffers of the reference share
+// pointer, push counts and lags: one ring (L+1, N, 3, J) (slot-major: a step writes one contiguous slab).  Host-known scalars
+// replace the reference's host syncs: `step` = appends so far (pointer = step mod (L+1)), pushes of env e = step - reset_step[e]
+// (reset_step[e] = the step index of the first append after its last reset).  A fresh env (zero pushes) fills every slot with
+// its first sample (circular_buffer.py:141-146); the sample read back is `min(lag, pushes - 1)` appends old (:160-165).
+// lookup (K,3) != NULL: angle-dependent torque limit by linear interpolation (linear_interpolation.py:54-86) after the PD law.
+__global__ void __launch_bounds__(256)
+k_actuator_delayed_pd(int64_t N, int J, int L1, int64_t step, const int32_t* __restrict__ lags, const int64_t* __restrict__ reset_step,
+                      float* __restrict__ ring, const float* __restrict__ q_des, const float* __restrict__ qd_des,
+                      const float* __restrict__ ff, const float* __restrict__ q, const float* __restrict__ qd,
+                      const float* __restrict__ kp, const float* __restrict__ kd, const float* __restrict__ elim,
+                      const float* __restrict__ lookup, int K, float* __restrict__ computed, float* __restrict__ applied) {
+    const int64_t n = N * J;
+    const int ptr = (int)(step % L1);
+    const int64_t slot = N * 3 * (int64_t)J;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / J;
+        const int j = (int)(i - e * J);
+        const int64_t pushes = step - reset_step[e];  // before this append
+        const float in[3] = {q_des[i], qd_des ? qd_des[i] : 0.0f, ff ? ff[i] : 0.0f};
+        float* base = ring + (e * 3) * (int64_t)J + j;
+        float d[3];
+        if (pushes <= 0) {
+            for (int sl = 0; sl < L1; ++sl)
+                for (int c = 0; c < 3; ++c) base[sl * slot + c * J] = in[c];
+            for (int c = 0; c < 3; ++c) d[c] = in[c];
+        } else {
+            const int64_t valid = min((int64_t)lags[e], pushes);  // min(lag, pushes_after - 1)
+            int idx = (int)((ptr - valid) % L1);
+            if (idx < 0) idx += L1;
+            for (int c = 0; c < 3; ++c) {
+                base[ptr * slot + c * J] = in[c];
+                d[c] = valid == 0 ? in[c] : base[idx * slot + c * J];
+            }
+        }
+        const float qi = q[i];
+        const float c = kp[i] * (d[0] - qi) + kd[i] * (d[1] - qd[i]) + d[2];
+        float lim = elim ? elim[i] : __builtin_huge_valf();
+        float a = fminf(fmaxf(c, -lim), lim);
+        if (lookup) {
+            int ns = 0;
+            for (int k = 0; k < K; ++k) ns += lookup[3 * k] < qi;
+            const int lb = max(ns - 1, 0), ub = min(ns, K - 1);
+            const float xl = lookup[3 * lb], xu = lookup[3 * ub], yl = lookup[3 * lb + 2], yu = lookup[3 * ub + 2];
+            const float w = ub == lb ? 0.0f : (qi - xl) / (xu - xl);
+            lim = yl + w * (yu - yl);
+            a = fminf(fmaxf(a, -lim), lim);
+        }
+        computed[i] = c;
+        applied[i] = a;
+    }
+}
+
+extern "C" int imx_actuator_delayed_pd(int64_t N, int64_t J, int max_delay, int64_t step, const int32_t* time_lags_d,
+                                       const int64_t* reset_step_d, float* ring_d, const float* joint_pos_target_d,
+                                       const float* joint_vel_target_d, const float* effort_ff_d, const float* joint_pos_d,
+                                       const float* joint_vel_d, const float* stiffness_d, const float* damping_d,
+                                       const float* effort_limit_d, const float* lookup_d, int num_lookup,
+                                       float* computed_effort_d, float* applied_effort_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && J > 0 && max_delay >= 0 && max_delay < 1024 && step >= 0, "imx_actuator_delayed_pd: bad sizes");
+    IMX_REQUIRE(time_lags_d && reset_step_d && ring_d && joint_pos_target_d && joint_pos_d && joint_vel_d && stiffness_d && damping_d &&
+                    computed_effort_d && applied_effort_d, "imx_actuator_delayed_pd: null argument");
+    IMX_REQUIRE(!lookup_d || num_lookup > 0, "imx_actuator_delayed_pd: empty lookup table");  // linear_interpolation.py:46-47
+    const int64_t n = N * J;
+    hipLaunchKernelGGL(k_actuator_delayed_pd, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, N, (int)J, max_delay + 1, step, time_lags_d, reset_step_d, ring_d, joint_pos_target_d,
+                       joint_vel_target_d, effort_ff_d, joint_pos_d, joint_vel_d, stiffness_d, damping_d, effort_limit_d, lookup_d,
+                       num_lookup, computed_effort_d, applied_effort_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

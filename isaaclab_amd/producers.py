@@ -182,3 +182,58 @@ class PDActuator:
                                     p(self.velocity_limit), p(self.computed_effort), p(self.applied_effort),
                                     _lib.current_stream(self.stiffness.device)))
         return self.applied_effort
+
+
+class DelayedPDActuator:
+    """``DelayedPDActuator`` / ``RemotizedPDActuator`` ``.reset`` + ``.compute`` on libimx (reference
+    isaaclab/actuators/actuator_pd.py:289-412): the position / velocity / feed-forward commands pass through one shared delay ring
+    with a per-env lag re-drawn at reset, then the PD law; ``joint_parameter_lookup`` (K,3) adds the remotized angle-dependent
+    torque limit.  One launch per physics step, no host sync (the reference's ``CircularBuffer.append`` has a ``.tolist()``)."""
+
+    def __init__(self, stiffness, damping, min_delay: int, max_delay: int, effort_limit=None, joint_parameter_lookup=None):
+        if stiffness.device.type != "cuda":
+            raise RuntimeError("DelayedPDActuator needs a GPU: libimx has no CPU path")
+        if not 0 <= int(min_delay) <= int(max_delay):
+            raise ValueError(f"The minimum time lag cannot be negative or above the maximum. Received: {min_delay}, {max_delay}")
+        dev = stiffness.device
+        N, J = stiffness.shape
+        self.stiffness, self.damping = stiffness.contiguous(), damping.contiguous()
+        self.min_delay, self.max_delay = int(min_delay), int(max_delay)
+        self.lookup = None
+        if joint_parameter_lookup is not None:  # RemotizedPDActuator removes the box limits (:373-380)
+            self.lookup = torch.as_tensor(joint_parameter_lookup, dtype=torch.float32, device=dev).contiguous()
+            x = self.lookup[:, 0]
+            if self.lookup.numel() == 0:
+                raise ValueError("Input tensor x is empty!")
+            if bool(torch.any(x[1:] < x[:-1])):
+                raise ValueError("Input tensor x is not sorted in ascending order!")
+            effort_limit = None
+        self.effort_limit = None if effort_limit is None else effort_limit.contiguous()
+        self.ring = torch.zeros(self.max_delay + 1, N, 3, J, device=dev)
+        self.time_lags = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.reset_step = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.step = 0
+        self.computed_effort = torch.zeros_like(self.stiffness)
+        self.applied_effort = torch.zeros_like(self.stiffness)
+
+    def reset(self, env_ids=None, time_lags=None):
+        """New random lag in [min_delay, max_delay] for ``env_ids`` (``time_lags`` overrides the draw: parity tests) and an empty
+        delay line: the next sample fills it."""
+        N = self.stiffness.shape[0]
+        ids = slice(None) if env_ids is None else env_ids
+        n = N if env_ids is None else len(env_ids)
+        if time_lags is None:
+            time_lags = torch.randint(self.min_delay, self.max_delay + 1, (n,), dtype=torch.int32, device=self.stiffness.device)
+        self.time_lags[ids] = time_lags.to(self.time_lags)
+        self.reset_step[ids] = self.step
+
+    def compute(self, joint_pos_target, joint_pos, joint_vel, joint_vel_target=None, effort_ff=None):
+        N, J = self.stiffness.shape
+        p = _lib.ptr
+        check(lib().imx_actuator_delayed_pd(N, J, self.max_delay, self.step, p(self.time_lags), p(self.reset_step), p(self.ring),
+                                            p(joint_pos_target), p(joint_vel_target), p(effort_ff), p(joint_pos), p(joint_vel),
+                                            p(self.stiffness), p(self.damping), p(self.effort_limit), p(self.lookup),
+                                            0 if self.lookup is None else self.lookup.shape[0], p(self.computed_effort),
+                                            p(self.applied_effort), _lib.current_stream(self.stiffness.device)))
+        self.step += 1
+        return self.applied_effort

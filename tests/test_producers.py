@@ -326,3 +326,60 @@ def test_actuator_hip_matches_reference():
         assert_close(act.computed_effort, c(f"{tag}/computed"), 1e-5, f"{tag} computed")
         assert_close(applied, c(f"{tag}/applied"), 1e-5, f"{tag} applied")
         assert float((applied != act.computed_effort).float().mean()) > 0.05  # the limits are exercised
+
+
+def _delayed_steps(z, tag):
+    meta = json.loads(str(z["meta"]))
+    for t in range(meta["delayed_steps"]):
+        pre = f"{tag}/step{t}/"
+        yield t, pre, (z[pre + "reset_ids"] if pre + "reset_ids" in z.files else None)
+
+
+def test_delayed_and_remotized_actuator_oracle_matches_reference():
+    """DelayedPDActuator / RemotizedPDActuator (actuator_pd.py:289-412) restated, against 9 steps of the real classes with
+    partial resets and re-drawn lags."""
+    from oracle.producers_oracle import DelayedPDOracle
+
+    z = _act_golden()
+    t_ = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    meta = json.loads(str(z["meta"]))
+    for tag in ("delayed", "remotized"):
+        o = DelayedPDOracle(meta["N"], meta["J"], meta["max_delay"], t_("stiffness"), t_("damping"), t_("effort_limit"),
+                            t_("remotized/lookup") if tag == "remotized" else None)
+        changed = 0
+        for t, pre, ids in _delayed_steps(z, tag):
+            if ids is not None:
+                o.reset(torch.from_numpy(ids), t_(pre + "time_lags"))
+            c, a = o.compute(t_(pre + "q_des"), t_(pre + "qd_des"), t_(pre + "ff"), t_(pre + "q"), t_(pre + "qd"))
+            assert_close(c, t_(pre + "computed"), 1e-6, f"{tag} step {t} computed")
+            assert_close(a, t_(pre + "applied"), 1e-6, f"{tag} step {t} applied")
+            undelayed = t_("stiffness") * (t_(pre + "q_des") - t_(pre + "q")) + t_("damping") * (t_(pre + "qd_des") - t_(pre + "qd")) + t_(pre + "ff")
+            changed += int((undelayed - c).abs().max() > 1e-3)
+        assert changed >= 6  # the delay line is exercised
+
+
+@pytest.mark.gpu
+def test_delayed_and_remotized_actuator_hip_matches_reference():
+    from isaaclab_amd.producers import DelayedPDActuator
+
+    z = _act_golden()
+    c_ = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    meta = json.loads(str(z["meta"]))
+    for tag in ("delayed", "remotized"):
+        act = DelayedPDActuator(c_("stiffness"), c_("damping"), 0, meta["max_delay"], effort_limit=c_("effort_limit"),
+                                joint_parameter_lookup=z["remotized/lookup"] if tag == "remotized" else None)
+        clipped = 0.0
+        for t, pre, ids in _delayed_steps(z, tag):
+            if ids is not None:
+                act.reset(torch.from_numpy(ids).cuda(), c_(pre + "time_lags"))
+            applied = act.compute(c_(pre + "q_des"), c_(pre + "q"), c_(pre + "qd"), c_(pre + "qd_des"), c_(pre + "ff"))
+            assert_close(act.computed_effort, c_(pre + "computed"), 1e-5, f"{tag} step {t} computed")
+            assert_close(applied, c_(pre + "applied"), 1e-5, f"{tag} step {t} applied")
+            clipped += float((applied != act.computed_effort).float().mean())
+        assert clipped / meta["delayed_steps"] > 0.05
+    # a drawn lag stays inside [min_delay, max_delay]
+    act = DelayedPDActuator(c_("stiffness"), c_("damping"), 1, 3)
+    act.reset()
+    assert int(act.time_lags.min()) >= 1 and int(act.time_lags.max()) <= 3
+    with pytest.raises(ValueError):
+        DelayedPDActuator(c_("stiffness"), c_("damping"), 3, 1)
