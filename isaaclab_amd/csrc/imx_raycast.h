@@ -159,6 +159,26 @@ IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_,
     }
 }
 
+// the references of a GENERAL / GENERAL_IND cell after its first pair (which the descriptor itself carries)
+IMX_DEV void vertical_cell_tail(const MeshView& m, int32_t d, float ox, float oy, float oz, bool flip, float Sz, float dz,
+                                float& best, int32_t& face) {
+    int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
+    if ((d & 3) == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
+    const int end = g.x + g.y;
+    for (int k = g.x + 2; k < end; k += 2) {  // the rest of the list: one 16-byte load gives the next two ids
+        const int4 rr = m.refs[k >> 1];
+        const float4* p = m.tri_rec + (size_t)rr.x * 3;
+        const float4* p2 = m.tri_rec + (size_t)rr.z * 3;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
+        vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
+                     best, face);
+        vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
+                     best, face);
+        if (flip && face >= 0 && __int_as_float(rr.w) < oz + best * dz) break;
+    }
+}
+
 IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
                            float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
@@ -187,21 +207,7 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
             // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
             if (flip && face >= 0 && __int_as_float(d4.w) < oz + best * dz) return;
         }
-        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
-        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
-        const int end = g.x + g.y;
-        for (int k = g.x + 2; k < end; k += 2) {  // the rest of the list: one 16-byte load gives the next two ids
-            const int4 rr = m.refs[k >> 1];
-            const float4* p = m.tri_rec + (size_t)rr.x * 3;
-            const float4* p2 = m.tri_rec + (size_t)rr.z * 3;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
-            vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
-                         best, face);
-            vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
-                         best, face);
-            if (flip && face >= 0 && __int_as_float(rr.w) < oz + best * dz) break;
-        }
+        vertical_cell_tail(m, d, ox, oy, oz, flip, Sz, dz, best, face);
     }
 }
 

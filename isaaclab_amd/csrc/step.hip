@@ -584,44 +584,84 @@ k_frame(PlanView P, int64_t N, imx_state_t S, float* __restrict__ frame) {
 // register-light stream: xcol (four 16-byte loads) -> value -> noise/clip/scale -> obs[e*D + c]; consecutive lanes
 // write consecutive floats of one obs row.  The ray path is cast_ray_vertical (imx_raycast.h): cell descriptor and
 // the four shared lattice corners are loaded together -- one dependent memory level per ray on height-field terrain.
+// value of one non-ray observation column (every op but HEIGHT_SCAN); es = the env's frame (k_frame)
+IMX_DEV float obs_plain_value(const PlanView& P, const imx_state_t& S, const imx_buffers_t& Bf, const float* __restrict__ es,
+                              int64_t e, const XCol& x) {
+    const int32_t* __restrict__ W = P.w;
+    const int op = x.a.y, j = x.a.z, flags = x.a.w, aux = x.c.z, J = P.J;
+    switch (op) {
+        case IMX_O_BASE_POS_Z: return es[11];
+        case IMX_O_BASE_LIN_VEL: return es[0 + j];
+        case IMX_O_BASE_ANG_VEL: return es[3 + j];
+        case IMX_O_PROJECTED_GRAVITY: return es[6 + j];
+        case IMX_O_ROOT_POS_W: return es[9 + j] - S.env_origins[e * 3 + j];
+        case IMX_O_ROOT_QUAT_W: return ((flags & IMX_F_QUAT_UNIQUE) && es[12] < 0.0f) ? -es[12 + j] : es[12 + j];
+        case IMX_O_ROOT_LIN_VEL_W: return S.root_lin_vel_w[e * 3 + j];
+        case IMX_O_ROOT_ANG_VEL_W: return S.root_ang_vel_w[e * 3 + j];
+        case IMX_O_JOINT_POS: return S.joint_pos[e * J + aux];
+        case IMX_O_JOINT_POS_REL: return S.joint_pos[e * J + aux] - S.default_joint_pos[e * J + aux];
+        case IMX_O_JOINT_POS_LIMIT_NORMALIZED: {  // scale_transform (utils/math.py:22-40)
+            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * J + aux];
+            const float offset = (lim.x + lim.y) * 0.5f;
+            return 2.0f * (S.joint_pos[e * J + aux] - offset) / (lim.y - lim.x);
+        }
+        case IMX_O_JOINT_VEL: return S.joint_vel[e * J + aux];
+        case IMX_O_JOINT_VEL_REL: return S.joint_vel[e * J + aux] - S.default_joint_vel[e * J + aux];
+        case IMX_O_LAST_ACTION: return Bf.action[e * P.A + j];
+        case IMX_O_GENERATED_COMMANDS: return S.command[e * P.CMD + j];
+        case IMX_O_EXTERNAL: return S.ext_obs[e * (int64_t)W[IMX_H_NEXT_OBS] + aux + j];
+        default: return 0.0f;
+    }
+}
+
+// modifiers -> noise -> clip -> scale -> history window -> obs[e][c] for computed column i (observation_manager.py:305-335)
+IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& x, int i, float v, int64_t e, int corrupt,
+                        bool fill_all, const float* __restrict__ noise_u, uint64_t seed, uint32_t step) {
+    const int D = P.D, c = x.a.x;
+    if (x.a.w & IMX_F_MODIFIERS)
+        v = apply_modifiers(P.w, P.xmod_off + 4 * i, v, Bf.mod_state + e * P.MS, fill_all || Bf.reset_buf[e]);
+    const float vp = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
+    float* o = Bf.obs + e * D + c;  // newest slot
+    const int hist = x.d.z;
+    if (hist > 1) {
+        // CircularBuffer.append (utils/buffers/circular_buffer.py:107-135) on the window kept in the obs row itself: this
+        // lane owns element j of every slot.  Envs reset this step (or all, at env.reset) have zero pushes: every slot
+        // takes the first value; otherwise the window slides by one.
+        const int hs = x.d.w;
+        if (fill_all || Bf.reset_buf[e]) {
+            for (int h = 1; h < hist; ++h) o[-h * hs] = vp;
+        } else {
+            for (int h = hist - 1; h >= 1; --h) o[-h * hs] = o[-(h - 1) * hs];
+        }
+    }
+    *o = vp;
+}
+
+#ifdef IMX_TRACE  // tools/trace_kobs.py only: per-wave start / end stamps (100 MHz wall clock) and placement; never in libimx.so
+__device__ uint64_t* g_trace = nullptr;
+extern "C" int imx_debug_trace(uint64_t* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)); }
+#endif
+
 template <bool GENERAL_RAYS>
 __global__ void __launch_bounds__(256)
 k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
       const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
     const int64_t e = blockIdx.x;
     const int32_t* __restrict__ W = P.w;
-    const int D = P.D, J = P.J;
     const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
     const uint32_t step = (uint32_t)Bf.counters[2];
     const float pz = es[11];
     const float yw = es[16], yz = es[17], px = es[9], py = es[10];
     const bool fill_all = (corrupt & 2) != 0;
     corrupt &= 1;
+#ifdef IMX_TRACE
+    const uint64_t trace_t0 = wall_clock64();
+#endif
     for (int i = threadIdx.x; i < P.DC; i += blockDim.x) {
         const XCol x = load_xcol(W, P.xcol_off, i);
-        const int c = x.a.x, op = x.a.y, j = x.a.z, flags = x.a.w, aux = x.c.z;
+        const int op = x.a.y, j = x.a.z;
         float v = 0.0f;
         switch (op) {
-            case IMX_O_BASE_POS_Z: v = pz; break;
-            case IMX_O_BASE_LIN_VEL: v = es[0 + j]; break;
-            case IMX_O_BASE_ANG_VEL: v = es[3 + j]; break;
-            case IMX_O_PROJECTED_GRAVITY: v = es[6 + j]; break;
-            case IMX_O_ROOT_POS_W: v = es[9 + j] - S.env_origins[e * 3 + j]; break;
-            case IMX_O_ROOT_QUAT_W: v = ((flags & IMX_F_QUAT_UNIQUE) && es[12] < 0.0f) ? -es[12 + j] : es[12 + j]; break;
-            case IMX_O_ROOT_LIN_VEL_W: v = S.root_lin_vel_w[e * 3 + j]; break;
-            case IMX_O_ROOT_ANG_VEL_W: v = S.root_ang_vel_w[e * 3 + j]; break;
-            case IMX_O_JOINT_POS: v = S.joint_pos[e * J + aux]; break;
-            case IMX_O_JOINT_POS_REL: v = S.joint_pos[e * J + aux] - S.default_joint_pos[e * J + aux]; break;
-            case IMX_O_JOINT_POS_LIMIT_NORMALIZED: {  // scale_transform (utils/math.py:22-40)
-                const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * J + aux];
-                const float offset = (lim.x + lim.y) * 0.5f;
-                v = 2.0f * (S.joint_pos[e * J + aux] - offset) / (lim.y - lim.x);
-            } break;
-            case IMX_O_JOINT_VEL: v = S.joint_vel[e * J + aux]; break;
-            case IMX_O_JOINT_VEL_REL: v = S.joint_vel[e * J + aux] - S.default_joint_vel[e * J + aux]; break;
-            case IMX_O_LAST_ACTION: v = Bf.action[e * P.A + j]; break;
-            case IMX_O_GENERATED_COMMANDS: v = S.command[e * P.CMD + j]; break;
-            case IMX_O_EXTERNAL: v = S.ext_obs[e * (int64_t)W[IMX_H_NEXT_OBS] + aux + j]; break;
             case IMX_O_HEIGHT_SCAN: {
                 // RayCaster._update_buffers_impl (ray_caster.py:242-260) + height_scan (observations.py:165-173)
                 const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
@@ -649,26 +689,18 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
                 }
                 v = pz - hz - f_of(x.b.x);
             } break;
-            default: break;
+            default: v = obs_plain_value(P, S, Bf, es, e, x); break;
         }
-        if (flags & IMX_F_MODIFIERS)
-            v = apply_modifiers(W, P.xmod_off + 4 * i, v, Bf.mod_state + e * P.MS, fill_all || Bf.reset_buf[e]);
-        const float vp = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
-        float* o = Bf.obs + e * D + c;  // newest slot
-        const int hist = x.d.z;
-        if (hist > 1) {
-            // CircularBuffer.append (utils/buffers/circular_buffer.py:107-135) on the window kept in the obs row itself: this
-            // lane owns element j of every slot.  Envs reset this step (or all, at env.reset) have zero pushes: every slot
-            // takes the first value; otherwise the window slides by one.
-            const int hs = x.d.w;
-            if (fill_all || Bf.reset_buf[e]) {
-                for (int h = 1; h < hist; ++h) o[-h * hs] = vp;
-            } else {
-                for (int h = hist - 1; h >= 1; --h) o[-h * hs] = o[-(h - 1) * hs];
-            }
-        }
-        *o = vp;
+        obs_finish(P, Bf, x, i, v, e, corrupt, fill_all, noise_u, seed, step);
     }
+#ifdef IMX_TRACE
+    if (g_trace && (threadIdx.x & 63) == 0) {
+        uint64_t* t = g_trace + ((size_t)e * 4 + (threadIdx.x >> 6)) * 4;
+        t[0] = trace_t0; t[1] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID (wave/simd/cu/sh/se ids)
+        t[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------- root frame
