@@ -117,6 +117,10 @@ def lib():
         from . import build as _build
 
         _build.build()
+    # torch first: libimx.so must bind to the HIP runtime torch ships and has (or will have) initialised -- loaded on its own it pulls
+    # /opt/rocm's libamdhip64 in, and a process with two HIP runtimes sees no GPU from the second one ("no GPU visible")
+    import torch  # noqa: F401
+
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # fail loudly: never substitute another implementation
