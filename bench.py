@@ -313,6 +313,8 @@ def main():
         "config": {"workload": f"{args.task}, {args.num_envs} envs/GPU, T={T}, 5 epochs x 4 minibatches, "
                                f"terrain {ntri} triangles, {args.snapshots} state snapshots resident in HBM",
                    "parallelism": f"dp{world}", "rollout": "eager" if args.no_graph else "hipGraph",
+                   "update": ("hipGraph" if getattr(runner.alg, "_update_g", None) is not None else "eager")
+                   + (" (measured eager %.2f ms, graph %.2f ms)" % runner.alg._update_times_ms if hasattr(runner.alg, "_update_times_ms") else ""),
                    "policy_params": runner.alg.bucket.numel},
         "phase_ms": {"collect_plus_gae": collect_ms, "update": update_ms},
     }

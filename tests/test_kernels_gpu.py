@@ -530,3 +530,54 @@ def test_whole_update_matches_torch_reference(libimx):
         assert err <= 2e-5 * max(1.0, float(q.abs().max())), f"{name}: max err {err:.2e} after {kw['num_learning_epochs'] * kw['num_mini_batches']} optimiser steps"
     stats = alg.loss_dict()
     assert all(np.isfinite(x) for x in stats.values())
+
+
+@pytest.mark.gpu
+def test_update_graph_replay_equals_eager_update(libimx):
+    """PPO.update captured as one hipGraph (update_graph, used by the runner with use_graph=True) against the eager update: same
+    storage, same seed, six updates each -- the captured torch.randperm consumes the generator exactly like the eager one, so
+    parameters, Adam state, learning rate and logged losses must agree to the last bit."""
+    import copy
+
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    T, N, D, A = 8, 96, 48, 12
+    torch.manual_seed(3)
+    pol0 = ActorCritic(D, D, A, actor_hidden_dims=[128, 64], critic_hidden_dims=[128, 64], init_noise_std=1.0)
+    kw = dict(num_learning_epochs=2, num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
+              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    g = torch.Generator().manual_seed(8)
+    obs = torch.randn(T, N, D, generator=g)
+    noise = torch.randn(T, N, A, generator=g)
+    ret_noise, adv = 0.3 * torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
+    results = []
+    for graph in (False, True):
+        alg = PPO(copy.deepcopy(pol0), device="cuda:0", **kw)
+        alg.update_graph = graph
+        alg.init_storage("rl", N, T, (D,), (0,), (A,))
+        torch.manual_seed(1234)
+        stats = []
+        for it in range(6):  # graph mode: eager, eager (timed), capture + replay, replay (timed), choice, chosen
+            if graph and it == 4:
+                alg._update_t = "graph"  # pin the choice: this test is about the equality, not about which is faster here
+            st = alg.storage
+            st.observations.copy_(obs + 0.1 * it)
+            with torch.no_grad():
+                mu = alg.policy.actor(st.observations.flatten(0, 1)).view(T, N, A)
+                val = alg.policy.critic(st.observations.flatten(0, 1)).view(T, N, 1)
+            sigma = alg.policy.std.detach().expand(T, N, A).contiguous()
+            act = mu + sigma * noise.cuda()
+            st.mu.copy_(mu); st.sigma.copy_(sigma); st.actions.copy_(act); st.values.copy_(val)
+            st.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+            st.returns.copy_(val + ret_noise.cuda())
+            st.advantages.copy_(adv)
+            st.step = T
+            alg.update()
+            stats.append(alg.loss_dict())
+        torch.cuda.synchronize()
+        assert (alg._update_g is not None) == graph
+        results.append((alg.bucket.flat.clone(), alg.bucket.exp_avg.clone(), alg.bucket.exp_avg_sq.clone(), alg.learning_rate, stats))
+    (p0, m0, v0, lr0, s0), (p1, m1, v1, lr1, s1) = results
+    assert lr0 == lr1 and s0 == s1
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
