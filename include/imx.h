@@ -273,6 +273,12 @@ int imx_ppo_loss_bwd(int64_t M, int64_t A, const float* mu_d, const float* sigma
                      float value_loss_coef, float entropy_coef, float grad_scale, float* dmu_d, float* dsigma_d,
                      float* dvalue_d, imx_stream_t stream);
 
+/* out[c] = sum_m x[m][c] * (y ? y[m][c] : 1), x / y (M,A) row-major, A <= 64: the action-noise gradient from the per-sample
+ * dsigma (``std.grad = dsigma.sum(0)``, or ``(dsigma * sigma).sum(0)`` for the log-std parametrisation of rsl_rl's ActorCritic).
+ * Two launches, fixed summation order.  scratch_d: imx_colsum_scratch_bytes() bytes. */
+size_t imx_colsum_scratch_bytes(void);
+int imx_colsum(int64_t M, int64_t A, const float* x_d, const float* y_d, float* out_d, void* scratch_d, imx_stream_t stream);
+
 /* torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (as used by rsl_rl PPO.update) on one flat fp32 bucket.
  * lr_d / grad_norm_d are DEVICE scalars (adaptive-KL learning rate, ||g||_2); grad_norm_d NULL = no clipping.
  * step = 1-based Adam step count. */

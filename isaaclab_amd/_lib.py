@@ -67,6 +67,8 @@ _SIGNATURES = {
                               c_float, c_int64, c_void_p]),
     "imx_adam_update": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float,
                                 c_float, c_float, c_float, c_void_p]),
+    "imx_colsum_scratch_bytes": (c_size_t, []),
+    "imx_colsum": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_adam_norm_scratch_bytes": (c_size_t, [c_int64]),
     "imx_adam_update_norm": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                      c_float, c_float, c_void_p, c_size_t, c_void_p]),

@@ -620,3 +620,46 @@ extern "C" int imx_rollout_post(int64_t N, const float* reward_d, const uint8_t*
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- column sums
+// out[c] = sum_m x[m][c] (* y[m][c]): the gradient of the action-noise parameter from the per-sample dsigma (M x A, A <= 64).
+// torch.sum(x, dim=0) on a 24576 x 37 tensor is one 320 us launch (its reduction kernel is laid out for long rows); here
+// COLSUM_BLOCKS workgroups each reduce a slab of rows -- a wave reads whole rows, lane = column, so loads are contiguous -- and
+// the last-arriving workgroup is NOT used: a second 64-thread launch adds the per-workgroup partials in a fixed order
+// (deterministic, and the two launches together are ~10 us).
+#define COLSUM_BLOCKS 256
+__global__ void __launch_bounds__(256)
+k_colsum_part(int64_t M, int A, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part) {
+    __shared__ float s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t rows = (M + COLSUM_BLOCKS - 1) / COLSUM_BLOCKS;
+    const int64_t r0 = blockIdx.x * rows, r1 = min(r0 + rows, M);
+    float acc = 0.0f;
+    if (lane < A)
+        for (int64_t r = r0 + wv; r < r1; r += 4) acc += y ? x[r * A + lane] * y[r * A + lane] : x[r * A + lane];
+    s[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && lane < A) part[(size_t)blockIdx.x * 64 + lane] = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+}
+__global__ void __launch_bounds__(64) k_colsum_final(int A, const float* __restrict__ part, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= A) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int b = 0; b < COLSUM_BLOCKS; b += 4) {
+        a0 += part[(size_t)b * 64 + c]; a1 += part[(size_t)(b + 1) * 64 + c];
+        a2 += part[(size_t)(b + 2) * 64 + c]; a3 += part[(size_t)(b + 3) * 64 + c];
+    }
+    out[c] = (a0 + a1) + (a2 + a3);
+}
+
+extern "C" size_t imx_colsum_scratch_bytes(void) { return (size_t)COLSUM_BLOCKS * 64 * sizeof(float); }
+
+extern "C" int imx_colsum(int64_t M, int64_t A, const float* x_d, const float* y_d, float* out_d, void* scratch_d,
+                          imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && A > 0 && A <= 64 && x_d && out_d && scratch_d, "imx_colsum: bad arguments (A <= 64)");
+    float* part = reinterpret_cast<float*>(scratch_d);
+    hipLaunchKernelGGL(k_colsum_part, dim3(COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, M, (int)A, x_d, y_d, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)A, part, out_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

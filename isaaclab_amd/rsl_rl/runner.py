@@ -57,7 +57,7 @@ class OnPolicyRunner:
         self.tot_timesteps = 0
         self.tot_time = 0.0
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
-        self.alg.update_graph = self.use_graph and os.getenv("IMX_UPDATE_GRAPH", "1") == "1"
+        self.alg.update_graph = self.use_graph and os.getenv("IMX_UPDATE_GRAPH", "1") != "0"
         self._graph = None
         N = self.env.num_envs
         self._cur_reward_sum = torch.zeros(N, device=self.device)

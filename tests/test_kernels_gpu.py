@@ -581,3 +581,29 @@ def test_update_graph_replay_equals_eager_update(libimx):
     (p0, m0, v0, lr0, s0), (p1, m1, v1, lr1, s1) = results
     assert lr0 == lr1 and s0 == s1
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,A", [(24576, 12), (24576, 37), (1000, 64), (7, 1)])
+def test_colsum_matches_torch(libimx, M, A):
+    """imx_colsum (std / log-std gradient from the per-sample dsigma) against a float64 column sum; deterministic across calls."""
+    from isaaclab_amd import _lib
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + A)
+    x = torch.randn(M, A, generator=g).cuda()
+    y = (torch.rand(M, A, generator=g) + 0.5).cuda()
+    scratch = torch.empty(int(L.imx_colsum_scratch_bytes()), dtype=torch.uint8, device="cuda")
+    for other in (None, y):
+        out = torch.full((A,), float("nan"), device="cuda")
+        _lib.check(L.imx_colsum(M, A, x.data_ptr(), None if other is None else other.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+                                _lib.current_stream(x.device)))
+        ref = (x.double() * (1.0 if other is None else other.double())).sum(0)
+        scale = float((x.double() * (1.0 if other is None else other.double())).abs().sum(0).max())
+        assert float((out.double() - ref).abs().max()) <= 1e-6 * scale
+        out2 = torch.empty_like(out)
+        _lib.check(L.imx_colsum(M, A, x.data_ptr(), None if other is None else other.data_ptr(), out2.data_ptr(), scratch.data_ptr(),
+                                _lib.current_stream(x.device)))
+        assert torch.equal(out, out2)
+    with pytest.raises(_lib.ImxError):
+        _lib.check(L.imx_colsum(M, 65, x.data_ptr(), None, out.data_ptr(), scratch.data_ptr(), _lib.current_stream(x.device)))
