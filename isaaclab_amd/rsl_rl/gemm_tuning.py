@@ -33,6 +33,8 @@ def enable_recorded_gemm_tuning() -> bool:
         if tune:
             tunable.set_filename(os.environ.get("IMX_GEMM_TUNE_FILE", os.path.join("gpurun_out", "tunableop_gfx950.csv")), True)
         elif os.path.exists(RECORDED):
+            if hasattr(tunable, "write_file_on_exit"):  # older torch rewrote the file at exit; 2.10 appends only while tuning
+                tunable.write_file_on_exit(False)  # read-only: eight ranks exiting together must never rewrite the in-tree table
             tunable.set_filename(RECORDED, False)  # every rank reads the same recorded table
             tunable.read_file(RECORDED)
         _done = True
