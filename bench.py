@@ -107,12 +107,12 @@ def time_obs_kernel(env, launches=200):
     """Average duration of k_obs from HIP events on the stream it is launched on (torch's current stream)."""
     dev = env.device
     for _ in range(10):
-        env._compute_observations()
+        env._compute_observations()  # k_frame + k_obs: the frame table of this state is current from here on
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream(dev))
     for _ in range(launches):
-        env._compute_observations()
+        env._compute_observations(frame_current=True)  # k_obs alone, as in env.step()
     e1.record(torch.cuda.current_stream(dev))
     torch.cuda.synchronize(dev)
     return e0.elapsed_time(e1) * 1e-3 / launches  # seconds per launch

@@ -222,7 +222,8 @@ int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx
  * counter-based RNG keyed by (seed, step counter, env, column).  ray_hits_out_d: optional (N,R,3).
  * Terms with ObservationTermCfg.history_length > 0 keep their flattened (H, d) window (oldest first; CircularBuffer,
  * utils/buffers/circular_buffer.py:107-135) in the obs row itself: envs flagged in buf->reset_buf -- or every env when bit 1
- * of enable_corruption is set (env.reset()) -- take the new value in every slot, the others slide by one. */
+ * of enable_corruption is set (env.reset()) -- take the new value in every slot, the others slide by one.  * enable_corruption bit 2 (value 4): the per-env frame table (root-frame vectors, scanner yaw) is current -- imx_terminations_rewards was
+ * called with root_pos_w on the SAME state tensors since they last changed and wrote it -- so the k_frame launch is skipped. */
 int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
                      const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
                      float* ray_hits_out_d, imx_stream_t stream);

@@ -157,7 +157,7 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
 // reward is bit-identical to a single-wave sequential evaluation.
 #define IMX_TR_WAVES 8
 __global__ void __launch_bounds__(64 * IMX_TR_WAVES)
-k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc) {
+k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame) {
     extern __shared__ float s_val[];  // [nrew][64]
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -181,6 +181,21 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     quat_rotate_inverse(qw, qx, qy, qz, lwx, lwy, lwz, lbx, lby, lbz);
     quat_rotate_inverse(qw, qx, qy, qz, awx, awy, awz, abx, aby, abz);
     quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, pgx, pgy, pgz);
+
+    // -- the env's frame table for the observation kernel of the same step (what k_frame writes: same functions, same inputs, so
+    //    bit-identical); the last wave has the fewest reward terms to evaluate
+    if (frame && wv == IMX_TR_WAVES - 1 && live) {
+        float4 o[5];
+        o[0] = make_float4(lbx, lby, lbz, abx);
+        o[1] = make_float4(aby, abz, pgx, pgy);
+        o[2] = make_float4(pgz, S.root_pos_w[e * 3], S.root_pos_w[e * 3 + 1], S.root_pos_w[e * 3 + 2]);
+        o[3] = q4;
+        o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, o[4].x, o[4].y);
+        float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] = o[k];
+    }
 
     // -- TerminationManager.compute (termination_manager.py:151-174)
     uint32_t term_bits = 0;
@@ -814,8 +829,10 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
     const unsigned grid = (unsigned)((N + 63) / 64);  // one block (4 waves) per 64 envs
     StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
     const size_t lds = (size_t)(plan->nrew > 0 ? plan->nrew : 1) * 64 * sizeof(float);
+    // with the root position at hand the kernel also leaves the frame table imx_observations needs (flag 4 there skips k_frame)
+    float* frame = st->root_pos_w ? reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N)) : nullptr;
     hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
-                       *bf, sc);
+                       *bf, sc, frame);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -858,7 +875,8 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     const PlanView pv = imx_plan_view(plan);
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
-    hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, frame);
+    if (!(enable_corruption & 4))  // bit 2: imx_terminations_rewards ran on this very state and left the frame table behind
+        hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, frame);
     // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
     const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
     if (vertical)

@@ -608,7 +608,7 @@ class ManagerBasedRLEnv:
                 self._ext_obs[:, c:c + term.dim] = fn(self, **term.params).reshape(self.num_envs, -1)
                 c += term.dim
 
-    def _compute_observations(self, fill_history: bool = False) -> torch.Tensor:
+    def _compute_observations(self, fill_history: bool = False, frame_current: bool = False) -> torch.Tensor:
         if self._ext_funcs["obs"]:
             self._eval_external("obs")
         hits = None
@@ -619,7 +619,7 @@ class ManagerBasedRLEnv:
         check(self._lib.imx_observations(
             self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
             self.terrain.handle if self.terrain is not None else None, _lib.ptr(self._noise_u), self.noise_seed,
-            (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0), hits, _lib.current_stream(self.device)))
+            (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0) | (4 if frame_current else 0), hits, _lib.current_stream(self.device)))
         return self._obs
 
     # ---- MDP operations ------------------------------------------------------------------------------------------
@@ -677,8 +677,9 @@ class ManagerBasedRLEnv:
         if self.command_term is not None:
             f = self.feed
             self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], self.reset_buf)
-        # -- observations on the post-reset state (one kernel, ray-cast fused)
-        obs = self._compute_observations()
+        # -- observations on the post-reset state (one kernel, ray-cast fused); imx_terminations_rewards left the frame table of
+        #    this state snapshot behind (the feed's root state is not rewritten by the reset events: they go to sim_writes)
+        obs = self._compute_observations(frame_current=True)
         return {"policy": obs}, self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     @property

@@ -313,3 +313,20 @@ def test_fused_rollout_storage_is_self_consistent(use_graph):
         assert_close(runner.last_obs, env.unwrapped._obs, 0, "last obs")
     assert st.dones.sum() > 0 and set(st.dones.unique().tolist()) <= {0, 1}
     assert torch.isfinite(st.rewards).all() and float(st.rewards.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_frame_table_from_the_step_kernel_equals_k_frame():
+    """env.step() lets imx_terminations_rewards leave the per-env frame table (root-frame vectors, scanner yaw) for imx_observations
+    (flag 4 skips k_frame): observations must be bit-identical to the ones computed with k_frame on the same state."""
+    g = Golden("Isaac-Velocity-Rough-Anymal-C-v0")
+    from isaaclab_amd.env import ManagerBasedRLEnv
+
+    env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), terrain=g.mesh())
+    env._noise_u = g.t("reset/noise_u").cuda()
+    env.reset()
+    for k in range(2):
+        env._noise_u.copy_(g.t(f"step{k}/noise_u"))
+        obs = env.step(g.t(f"step{k}/action").cuda())[0]["policy"].clone()  # frame written by the step kernel
+        again = env._compute_observations().clone()                          # k_frame on the same state
+        assert torch.equal(obs, again)
