@@ -78,7 +78,7 @@ IMX_DEV float max_hist_force(const float* __restrict__ F, int64_t e, int H, int 
     return m;
 }
 
-// scratch layout for k_term_rew (4-byte words, nw = number of 64-env groups = ceil(N/64))
+// scratch layout for k_term_rew (4-byte words, nw = number of env groups, sized for the smaller group: ceil(N/32))
 //   [0, nw*KA)               float  per-group partial sums of episode_sums over reset envs
 //   [.., + nw*NT)            int    per-group counts of term_dones over reset envs
 //   [.., + nw)               int    per-group reset counts
@@ -90,11 +90,11 @@ struct StepScratch {
     int* ids_local;
 };
 static inline size_t step_scratch_words(int64_t N, int KA, int NT) {
-    const size_t nw = (size_t)((N + 63) / 64);
+    const size_t nw = (size_t)((N + 31) / 32);
     return nw * KA + nw * NT + nw + nw * 64;
 }
 static inline StepScratch carve(void* base, int64_t N, int KA, int NT) {
-    const size_t nw = (size_t)((N + 63) / 64);
+    const size_t nw = (size_t)((N + 31) / 32);
     StepScratch s;
     s.log_part = (float*)base;
     s.term_part = (int*)(s.log_part + nw * KA);
@@ -155,15 +155,19 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
 // waves (4x the loads in flight per env), each wave finishing its own terms completely (value, episodic sum,
 // step_reward, reset-log partial).  The per-term values meet in LDS and wave 0 adds them IN TERM ORDER, so the
 // reward is bit-identical to a single-wave sequential evaluation.
+// G = envs per workgroup: 64 (every lane an env) or 32 (upper half-waves idle): at 4096 envs 64-env groups are only 64
+// workgroups on 256 CUs and the kernel is one latency chain long, so twice as many half-filled groups finish sooner; from
+// 16384 envs on the full groups win.
 #define IMX_TR_WAVES 8
+template <int G>
 __global__ void __launch_bounds__(64 * IMX_TR_WAVES)
 k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame) {
     extern __shared__ float s_val[];  // [nrew][64]
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t grp = blockIdx.x;
-    const int64_t e = grp * 64 + lane;
-    const bool live = e < N;
+    const int64_t e = grp * G + lane;
+    const bool live = lane < G && e < N;
     const int64_t ec = live ? e : N - 1;  // clamp: dead lanes compute on a valid env, never store
     const int J = P.J, Bn = P.B, H = P.H, A = P.A;
     const int32_t* __restrict__ W = P.w;
@@ -425,7 +429,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     }
     __syncthreads();
     if (!s_last) return;
-    const int nw = (int)((N + 63) / 64);
+    const int nw = (int)((N + G - 1) / G);
     const int T = blockDim.x;
     const int t = threadIdx.x;
     // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + 4 wave totals
@@ -454,7 +458,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
         const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
         for (int j = 0; j < c; ++j)
-            Bf.reset_env_ids[off + j] = (int64_t)w * 64 + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
+            Bf.reset_env_ids[off + j] = (int64_t)w * G + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
         off += c;
     }
     if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
@@ -826,13 +830,18 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
         }
     }
     if (plan->CMD > 0 && !st->command) IMX_FAIL("command tensor missing");
-    const unsigned grid = (unsigned)((N + 63) / 64);  // one block (4 waves) per 64 envs
+    const int G = N <= 8192 ? 32 : 64;  // envs per workgroup (see k_term_rew)
+    const unsigned grid = (unsigned)((N + G - 1) / G);
     StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
     const size_t lds = (size_t)(plan->nrew > 0 ? plan->nrew : 1) * 64 * sizeof(float);
     // with the root position at hand the kernel also leaves the frame table imx_observations needs (flag 4 there skips k_frame)
     float* frame = st->root_pos_w ? reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N)) : nullptr;
-    hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
-                       *bf, sc, frame);
+    if (G == 32)
+        hipLaunchKernelGGL(k_term_rew<32>, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
+                           *bf, sc, frame);
+    else
+        hipLaunchKernelGGL(k_term_rew<64>, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
+                           *bf, sc, frame);
     IMX_HIP(hipGetLastError());
     return 0;
 }
