@@ -307,6 +307,10 @@ int imx_adam_update_norm(int64_t n, float* param_d, const float* grad_d, float* 
  * width_floats[k] columns, one launch.  src_d / dst_d / width_floats are HOST arrays of device pointers / widths. */
 int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
                     const int32_t* width_floats, imx_stream_t stream);
+/* The same with a row pitch per destination array (floats, >= width; NULL = packed): a minibatch buffer whose rows start on 16-byte
+ * boundaries lets imx_mlp_dw read it with 16-byte loads when the observation width is not a multiple of four (235, 310). */
+int imx_gather_rows_pitched(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
+                            const int32_t* width_floats, const int32_t* dst_pitch_floats, imx_stream_t stream);
 
 /* rsl_rl PPO.act after the actor / critic GEMMs: sample a = mu + std*N(0,1) (counter-based in-kernel generator keyed by
  * seed and *step_counter_d), log-prob, and the transition written into slot t of the RolloutStorage (obs, actions,

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "imx_adam_update_norm": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                      c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "imx_gather_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imx_gather_rows_pitched": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_policy_act": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p] + [c_void_p] * 7
                        + [c_void_p]),
     "imx_rollout_post": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,

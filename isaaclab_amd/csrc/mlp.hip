@@ -567,7 +567,9 @@ static int mlp_dw_launch(const char* who, int64_t M, int N, int K, const float* 
     a.H = H_d; a.ldh = ldh; a.Dout = Dout_d; a.ldd = ldd; a.alpha = alpha;
     bool yvec = (N % 4 == 0) && (ldy % 4 == 0) && aligned16(dY_d);
     if (act) yvec = yvec && (ldh % 4 == 0) && aligned16(H_d) && (!Dout_d || ((ldd % 4 == 0) && aligned16(Dout_d)));
-    const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X_d);
+    // 16-byte loads of X need aligned rows; K itself may be ragged when the row pitch covers the last vector (the columns past K land in
+    // dW columns that are never written)
+    const bool xvec = (ldx % 4 == 0) && aligned16(X_d) && (K % 4 == 0 || ldx >= ((K + 3) & ~3));
     const dim3 grid((unsigned)(p.tn * p.tk * p.S)), block(512);
     hipStream_t st = (hipStream_t)stream;
 #define IMX_DW_LAUNCH(Y, X, A) hipLaunchKernelGGL((k_mlp_dw<Y, X, A>), grid, block, 0, st, a)

@@ -478,6 +478,7 @@ struct GatherArgs {
     const float* src[12];
     float* dst[12];
     int width[12];
+    int dpitch[12];  // row pitch of dst in floats (>= width)
     int offset[13];  // prefix sums of width
     int n;
 };
@@ -489,21 +490,21 @@ __global__ void __launch_bounds__(256) k_gather_rows(int64_t M, const int64_t* _
         const bool two = r1 < M;
         const int64_t s0 = idx[r0], s1 = two ? idx[r1] : 0;
         for (int k = 0; k < a.n; ++k) {
-            const int w = a.width[k];
+            const int w = a.width[k], dp = a.dpitch[k];
             const float* __restrict__ src = a.src[k];
             float* __restrict__ dst = a.dst[k];
             for (int c = lane; c < w; c += 64) {
                 const float v0 = src[s0 * w + c];
                 const float v1 = two ? src[s1 * w + c] : 0.0f;
-                dst[r0 * w + c] = v0;
-                if (two) dst[r1 * w + c] = v1;
+                dst[r0 * dp + c] = v0;
+                if (two) dst[r1 * dp + c] = v1;
             }
         }
     }
 }
 
-extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
-                               const int32_t* width_floats, imx_stream_t stream) {
+extern "C" int imx_gather_rows_pitched(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
+                                       const int32_t* width_floats, const int32_t* dst_pitch_floats, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && idx_d && n > 0 && n <= 12 && src_d && dst_d && width_floats, "imx_gather_rows: bad arguments");
     GatherArgs a;
     a.n = n;
@@ -512,13 +513,20 @@ extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const voi
         a.src[k] = k < n ? (const float*)src_d[k] : nullptr;
         a.dst[k] = k < n ? (float*)dst_d[k] : nullptr;
         a.width[k] = k < n ? width_floats[k] : 0;
+        a.dpitch[k] = k < n ? (dst_pitch_floats ? dst_pitch_floats[k] : width_floats[k]) : 0;
         IMX_REQUIRE(k >= n || (a.src[k] && a.dst[k] && a.width[k] > 0), "imx_gather_rows: array %d is null or empty", k);
+        IMX_REQUIRE(k >= n || a.dpitch[k] >= a.width[k], "imx_gather_rows: array %d: destination pitch %d < width %d", k, a.dpitch[k], a.width[k]);
         a.offset[k + 1] = a.offset[k] + a.width[k];
     }
     const unsigned grid = (unsigned)std::min<int64_t>((M + 7) / 8, 4096);  // 4 waves per block, 2 rows per wave and trip
     hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, idx_d, a);
     IMX_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int imx_gather_rows(int64_t M, const int64_t* idx_d, int n, const void* const* src_d, void* const* dst_d,
+                               const int32_t* width_floats, imx_stream_t stream) {
+    return imx_gather_rows_pitched(M, idx_d, n, src_d, dst_d, width_floats, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------- rollout step fusions

@@ -115,13 +115,17 @@ class RolloutStorage:
                  self.sigma.flatten(0, 1)]
         key = (M, len(srcs))
         if getattr(self, "_mb_key", None) != key:
-            self._mb_dst = [torch.empty(M, s.shape[1], device=self.device) for s in srcs]
+            # wide rows (observations) start on 16-byte boundaries: the dW kernel of the first layer reads them with 16-byte loads
+            # even when the width is ragged (235 -> pitch 236: 81.8 -> 71.2 us, tools/dw_pitch.py); the views keep the true width
+            pitch = [(s.shape[1] + 3) // 4 * 4 if s.shape[1] >= 16 else s.shape[1] for s in srcs]
+            self._mb_dst = [torch.empty(M, p, device=self.device)[:, :s.shape[1]] for s, p in zip(srcs, pitch)]
             self._mb_key = key
         dst = self._mb_dst
         n = len(srcs)
         src_p = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
         dst_p = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dst])
         widths = (ctypes.c_int32 * n)(*[s.shape[1] for s in srcs])
+        pitches = (ctypes.c_int32 * n)(*[d.stride(0) for d in dst])
         L = lib()
         stream = _lib.current_stream(torch.device(self.device))
         main = torch.cuda.current_stream(torch.device(self.device)) if copy_stream is not None else None
@@ -131,7 +135,7 @@ class RolloutStorage:
                 if copy_stream is not None:
                     copy_stream.wait_stream(main)
                     stream = copy_stream.cuda_stream
-                check(L.imx_gather_rows(M, idx.data_ptr(), n, src_p, dst_p, widths, stream))
+                check(L.imx_gather_rows_pitched(M, idx.data_ptr(), n, src_p, dst_p, widths, pitches, stream))
                 batch = tuple(dst) if self.privileged_observations is not None else (dst[0], dst[0]) + tuple(dst[1:])
                 if copy_stream is not None:
                     ready = torch.cuda.Event()
