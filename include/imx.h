@@ -438,6 +438,27 @@ int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int
 int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
                      int elu_in_place, float elu_alpha, imx_stream_t stream);
 
+/* imx_mlp_head_fwd followed by imx_ppo_loss_bwd in ONE launch: the lane that holds a sample's outputs computes the loss gradient
+ * from them right away (policy head: mode 1 -> dmu_d, dsigma_d from mu = y; value head, A = 1: mode 2 -> dvalue_d from value = y).
+ * Same arithmetic, same order as k_ppo_bwd (bit-identical gradients); saves a dependent launch on the update's critical chain. */
+typedef struct imx_head_loss {
+    int mode;                  /* 1 policy gradient, 2 value gradient */
+    int sigma_stride;          /* 0 (shared std) or A */
+    int use_clipped_value_loss;
+    float clip_param, value_loss_coef, entropy_coef, grad_scale;
+    const float* sigma_d;      /* mode 1 */
+    const float* actions_d;
+    const float* old_logp_d;
+    const float* advantages_d;
+    const float* returns_d;    /* mode 2 */
+    const float* old_values_d;
+    float* dmu_d;              /* mode 1 outputs (M,A) */
+    float* dsigma_d;
+    float* dvalue_d;           /* mode 2 output (M,1) */
+} imx_head_loss_t;
+int imx_mlp_head_fwd_loss(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                          int elu_in_place, float elu_alpha, const imx_head_loss_t* loss, imx_stream_t stream);
+
 /* Output layer backward in one pass over h: dW[A][K] = dY^T h, db[A] = colsum(dY), and the gradient handed to the layer
  * below, dprev[M][K] = (dY W) * ELU'(h) with ELU' taken from the saved output h (h > 0 ? 1 : h + elu_alpha; aten
  * elu_backward with is_result) when has_activation != 0, else dprev = dY W. */

@@ -31,6 +31,13 @@ class ImxBuffers(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in BUFFER_FIELDS]
 
 
+class ImxHeadLoss(ctypes.Structure):  # imx_head_loss_t
+    _fields_ = [("mode", ctypes.c_int), ("sigma_stride", ctypes.c_int), ("use_clipped_value_loss", ctypes.c_int),
+                ("clip_param", ctypes.c_float), ("value_loss_coef", ctypes.c_float), ("entropy_coef", ctypes.c_float),
+                ("grad_scale", ctypes.c_float)] + [(n, c_void_p) for n in (
+                    "sigma_d", "actions_d", "old_logp_d", "advantages_d", "returns_d", "old_values_d", "dmu_d", "dsigma_d", "dvalue_d")]
+
+
 class ImxError(RuntimeError):
     pass
 
@@ -104,6 +111,7 @@ _SIGNATURES = {
     "imx_mlp_infer": (c_int, [c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "imx_mlp_head_fwd_loss": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "imx_mlp_head_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
 }

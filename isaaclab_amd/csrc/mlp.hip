@@ -366,10 +366,11 @@ constexpr int HEAD_A = 64;  // widest output layer handled (actions / value): 37
 
 // ELU_IN: h holds the PRE-activation output of the layer below; ELU is applied on the way in and written back in place
 // (every element is read by exactly one lane), which saves that layer's separate activation pass.
-template <bool ELU_IN, int AMAX>
+#define IMX_HALF_LOG_2PI_F 0.91893853320467274178f
+template <bool ELU_IN, int AMAX, int LOSS>
 __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float* __restrict__ h, int64_t ldh,
                                                   const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y,
-                                                  float alpha) {
+                                                  float alpha, imx_head_loss_t L) {
     extern __shared__ float sW[];  // [A][K]
     for (int i = threadIdx.x; i < A * K; i += blockDim.x) sW[i] = W[i];
     __syncthreads();
@@ -409,6 +410,48 @@ __global__ void __launch_bounds__(256) k_head_fwd(int64_t M, int K, int A, float
 #pragma unroll
         for (int o = 0; o < AMAX; ++o)
             if (o < A) y[row * A + o] = acc[o];  // uniform condition
+        // the loss gradient straight from the outputs in registers: line by line k_ppo_bwd (rollout.hip), which stays the reference
+        if (LOSS == 1) {
+            const float inv_m = L.grad_scale / (float)M;
+            float logp = 0.0f;
+#pragma unroll
+            for (int o = 0; o < AMAX; ++o)
+                if (o < A) {
+                    const float m = acc[o], s = L.sigma_d[row * L.sigma_stride + o];
+                    const float d = L.actions_d[row * A + o] - m;
+                    logp += -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI_F;
+                }
+            const float ratio = expf(logp - L.old_logp_d[row]);
+            const float ad = L.advantages_d[row], clip = L.clip_param;
+            const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+            float dsur_dlogp;
+            if (s1 >= s2) dsur_dlogp = -ad * ratio;
+            else dsur_dlogp = (ratio > 1.0f - clip && ratio < 1.0f + clip) ? -ad * ratio : 0.0f;
+            const float g = dsur_dlogp * inv_m;
+#pragma unroll
+            for (int o = 0; o < AMAX; ++o)
+                if (o < A) {
+                    const float m = acc[o], s = L.sigma_d[row * L.sigma_stride + o];
+                    const float d = L.actions_d[row * A + o] - m;
+                    L.dmu_d[row * A + o] = g * (d / (s * s));
+                    L.dsigma_d[row * A + o] = g * ((d * d) / (s * s * s) - 1.0f / s) - L.entropy_coef * inv_m / s;
+                }
+        } else if (LOSS == 2) {
+            const float inv_m = L.grad_scale / (float)M;
+            const float v = acc[0], R = L.returns_d[row], clip = L.clip_param;
+            float dv;
+            if (L.use_clipped_value_loss) {
+                const float vo = L.old_values_d[row];
+                const float dlt = v - vo;
+                const float vc = vo + fminf(fmaxf(dlt, -clip), clip);
+                const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+                if (l1 >= l2) dv = 2.0f * (v - R);
+                else dv = (dlt > -clip && dlt < clip) ? 2.0f * (vc - R) : 0.0f;
+            } else {
+                dv = -2.0f * (R - v);
+            }
+            L.dvalue_d[row] = L.value_loss_coef * dv * inv_m;
+        }
     }
 }
 
@@ -634,22 +677,51 @@ extern "C" int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_
                          scratch_bytes, stream);
 }
 
-extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
-                                int elu_in_place, float elu_alpha, imx_stream_t stream) {
+static int head_fwd_launch(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                           int elu_in_place, float elu_alpha, const imx_head_loss_t* loss, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && h_d && W_d && b_d && y_d, "imx_mlp_head_fwd: bad arguments");
     IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_fwd: %d outputs (1..%d supported; wider layers are library GEMMs)", A, HEAD_A);
     IMX_REQUIRE(K >= 16 && K % 16 == 0 && K <= 2048 && ldh >= K && ldh % 4 == 0 && aligned16(h_d),
                 "imx_mlp_head_fwd: in-features %d (pitch %lld) must be a multiple of 16, 16-byte aligned rows", K, (long long)ldh);
     IMX_REQUIRE((size_t)A * K * sizeof(float) <= 64 * 1024, "imx_mlp_head_fwd: %d x %d weights do not fit the 64 KB of LDS used", A, K);
+    imx_head_loss_t L{};
+    int mode = 0;
+    if (loss) {
+        L = *loss;
+        mode = L.mode;
+        IMX_REQUIRE(mode == 1 || mode == 2, "imx_mlp_head_fwd_loss: mode %d (1 policy, 2 value)", mode);
+        if (mode == 1) {
+            IMX_REQUIRE(L.sigma_d && L.actions_d && L.old_logp_d && L.advantages_d && L.dmu_d && L.dsigma_d, "imx_mlp_head_fwd_loss: null policy argument");
+            IMX_REQUIRE(L.sigma_stride == 0 || L.sigma_stride == A, "imx_mlp_head_fwd_loss: sigma_stride must be 0 (shared std) or A");
+        } else {
+            IMX_REQUIRE(A == 1 && L.returns_d && L.dvalue_d && (!L.use_clipped_value_loss || L.old_values_d), "imx_mlp_head_fwd_loss: value head needs A = 1, returns, old values");
+        }
+    }
     const dim3 grid((unsigned)((M + 63) / 64)), block(256);
     const size_t lds = (size_t)A * K * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-#define IMX_HEAD_FWD(E, AM) hipLaunchKernelGGL((k_head_fwd<E, AM>), grid, block, lds, st, M, K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha)
-    if (A <= 16) { if (elu_in_place) IMX_HEAD_FWD(true, 16); else IMX_HEAD_FWD(false, 16); }
-    else { if (elu_in_place) IMX_HEAD_FWD(true, HEAD_A); else IMX_HEAD_FWD(false, HEAD_A); }
+#define IMX_HEAD_FWD(E, AM, LS) hipLaunchKernelGGL((k_head_fwd<E, AM, LS>), grid, block, lds, st, M, K, A, h_d, ldh, W_d, b_d, y_d, elu_alpha, L)
+#define IMX_HEAD_FWD_E(AM, LS) do { if (elu_in_place) IMX_HEAD_FWD(true, AM, LS); else IMX_HEAD_FWD(false, AM, LS); } while (0)
+    if (A <= 16) {
+        if (mode == 0) IMX_HEAD_FWD_E(16, 0); else if (mode == 1) IMX_HEAD_FWD_E(16, 1); else IMX_HEAD_FWD_E(16, 2);
+    } else {
+        if (mode == 0) IMX_HEAD_FWD_E(HEAD_A, 0); else if (mode == 1) IMX_HEAD_FWD_E(HEAD_A, 1); else IMX_HEAD_FWD_E(HEAD_A, 2);
+    }
+#undef IMX_HEAD_FWD_E
 #undef IMX_HEAD_FWD
     IMX_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int imx_mlp_head_fwd(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                                int elu_in_place, float elu_alpha, imx_stream_t stream) {
+    return head_fwd_launch(M, K, A, h_d, ldh, W_d, b_d, y_d, elu_in_place, elu_alpha, nullptr, stream);
+}
+
+extern "C" int imx_mlp_head_fwd_loss(int64_t M, int K, int A, float* h_d, int64_t ldh, const float* W_d, const float* b_d, float* y_d,
+                                     int elu_in_place, float elu_alpha, const imx_head_loss_t* loss, imx_stream_t stream) {
+    IMX_REQUIRE(loss, "imx_mlp_head_fwd_loss: null loss description");
+    return head_fwd_launch(M, K, A, h_d, ldh, W_d, b_d, y_d, elu_in_place, elu_alpha, loss, stream);
 }
 
 extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, const float* h_d, int64_t ldh, const float* W_d, float elu_alpha,

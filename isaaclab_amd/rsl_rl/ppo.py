@@ -17,6 +17,7 @@ MI355X-first structure of ``update()`` (same arithmetic as upstream):
 
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -221,9 +222,11 @@ class DeferredReductions:
             pass
 
 
-def mlp_forward(layers, x, out=None):
+def mlp_forward(layers, x, out=None, head_loss=None):
     """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
-    the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given)."""
+    the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given).  ``head_loss`` = {"loss": ImxHeadLoss}:
+    when the LAST layer goes through the head kernel, the loss gradient is computed in the same launch
+    (``imx_mlp_head_fwd_loss``) and ``head_loss["applied"]`` is set."""
     saved = [x]
     h = x
     pending_elu = None  # ELU of the last hidden layer is applied by the head kernel on its way in (in place)
@@ -233,9 +236,16 @@ def mlp_forward(layers, x, out=None):
                 z = out
             else:
                 z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
-            check(lib().imx_mlp_head_fwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
-                                         lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None),
-                                         float(pending_elu or 0.0), _lib.current_stream(h.device)))
+            if head_loss is not None and li == len(layers) - 1:
+                check(lib().imx_mlp_head_fwd_loss(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
+                                                  lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None),
+                                                  float(pending_elu or 0.0), ctypes.byref(head_loss["loss"]),
+                                                  _lib.current_stream(h.device)))
+                head_loss["applied"] = True
+            else:
+                check(lib().imx_mlp_head_fwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
+                                             lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None),
+                                             float(pending_elu or 0.0), _lib.current_stream(h.device)))
             pending_elu = None
         else:
             if pending_elu is not None:
@@ -458,18 +468,29 @@ class PPO:
 
         def actor_pass(st):
             nonlocal sigma
-            mu, saved_a = mlp_forward(self._actor_layers, obs)
+            hl = None
+            if sigma is not None:  # shared std: the head kernel computes the policy gradient from mu in the same launch
+                hl = {"loss": _lib.ImxHeadLoss(mode=1, sigma_stride=0, use_clipped_value_loss=vclip, clip_param=clipf, value_loss_coef=vcoef,
+                                               entropy_coef=ecoef, grad_scale=1.0, sigma_d=sigma.data_ptr(), actions_d=actions.data_ptr(),
+                                               old_logp_d=old_logp.data_ptr(), advantages_d=advantages.data_ptr(),
+                                               dmu_d=ws["dmu"].data_ptr(), dsigma_d=ws["dsigma"].data_ptr())}
+            mu, saved_a = mlp_forward(self._actor_layers, obs, head_loss=hl)
             if sigma is None:
                 sigma = torch.exp(pol.log_std).expand_as(mu).contiguous()
-            check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
-                                     advantages.data_ptr(), None, None, None, clipf, vclip, vcoef, ecoef, 1.0,
-                                     ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(), None, st))
+            if hl is None or not hl.get("applied"):
+                check(L.imx_ppo_loss_bwd(M, A, mu.data_ptr(), sigma.data_ptr(), sstride, actions.data_ptr(), old_logp.data_ptr(),
+                                         advantages.data_ptr(), None, None, None, clipf, vclip, vcoef, ecoef, 1.0,
+                                         ws["dmu"].data_ptr(), ws["dsigma"].data_ptr(), None, st))
             return mu, saved_a
 
         def critic_pass(st):
-            value, saved_c = mlp_forward(self._critic_layers, critic_obs)
-            check(L.imx_ppo_loss_bwd(M, A, None, None, sstride, None, None, None, returns.data_ptr(), value.data_ptr(),
-                                     target_values.data_ptr(), clipf, vclip, vcoef, ecoef, 1.0, None, None, ws["dvalue"].data_ptr(), st))
+            hl = {"loss": _lib.ImxHeadLoss(mode=2, sigma_stride=0, use_clipped_value_loss=vclip, clip_param=clipf, value_loss_coef=vcoef,
+                                           entropy_coef=ecoef, grad_scale=1.0, returns_d=returns.data_ptr(),
+                                           old_values_d=target_values.data_ptr(), dvalue_d=ws["dvalue"].data_ptr())}
+            value, saved_c = mlp_forward(self._critic_layers, critic_obs, head_loss=hl)
+            if not hl.get("applied"):
+                check(L.imx_ppo_loss_bwd(M, A, None, None, sstride, None, None, None, returns.data_ptr(), value.data_ptr(),
+                                         target_values.data_ptr(), clipf, vclip, vcoef, ecoef, 1.0, None, None, ws["dvalue"].data_ptr(), st))
             return value, saved_c
 
         def loss_values(mu, value, st):  # logging / adaptive-LR inputs and the sigma gradient: off the critical path

@@ -607,3 +607,56 @@ def test_colsum_matches_torch(libimx, M, A):
         assert torch.equal(out, out2)
     with pytest.raises(_lib.ImxError):
         _lib.check(L.imx_colsum(M, 65, x.data_ptr(), None, out.data_ptr(), scratch.data_ptr(), _lib.current_stream(x.device)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [12, 37, 1])
+def test_head_forward_with_fused_loss_gradient_equals_two_launches(libimx, A):
+    """imx_mlp_head_fwd_loss = imx_mlp_head_fwd + imx_ppo_loss_bwd in one launch: outputs and loss gradients bit-identical to
+    the two separate launches (policy head for A > 1, value head for A = 1)."""
+    import ctypes
+
+    from isaaclab_amd import _lib
+
+    L = _lib.lib()
+    M, K = 3000, 128
+    g = torch.Generator().manual_seed(40 + A)
+    h = torch.randn(M, K, generator=g).cuda()
+    W, b = (0.1 * torch.randn(A, K, generator=g)).cuda(), (0.1 * torch.randn(A, generator=g)).cuda()
+    sigma = (0.5 + torch.rand(A, generator=g)).cuda()
+    act = torch.randn(M, A, generator=g).cuda()
+    old_logp = (-1.0 - torch.rand(M, generator=g) * A).cuda()
+    adv, ret, old_v = torch.randn(M, generator=g).cuda(), torch.randn(M, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+    st = _lib.current_stream(h.device)
+    clip, vcoef, ecoef = 0.2, 1.0, 0.005
+    # two launches
+    h1, y1 = h.clone(), torch.empty(M, A, device="cuda")
+    _lib.check(L.imx_mlp_head_fwd(M, K, A, h1.data_ptr(), K, W.data_ptr(), b.data_ptr(), y1.data_ptr(), 1, 1.0, st))
+    dmu1, dsg1, dv1 = torch.empty(M, A, device="cuda"), torch.empty(M, A, device="cuda"), torch.empty(M, 1, device="cuda")
+    if A > 1:
+        _lib.check(L.imx_ppo_loss_bwd(M, A, y1.data_ptr(), sigma.data_ptr(), 0, act.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), None, None,
+                                      None, clip, 1, vcoef, ecoef, 1.0, dmu1.data_ptr(), dsg1.data_ptr(), None, st))
+    else:
+        _lib.check(L.imx_ppo_loss_bwd(M, A, None, None, 0, None, None, None, ret.data_ptr(), y1.data_ptr(), old_v.data_ptr(), clip, 1, vcoef,
+                                      ecoef, 1.0, None, None, dv1.data_ptr(), st))
+    # one launch
+    h2, y2 = h.clone(), torch.empty(M, A, device="cuda")
+    dmu2, dsg2, dv2 = torch.empty(M, A, device="cuda"), torch.empty(M, A, device="cuda"), torch.empty(M, 1, device="cuda")
+    if A > 1:
+        hl = _lib.ImxHeadLoss(mode=1, sigma_stride=0, use_clipped_value_loss=1, clip_param=clip, value_loss_coef=vcoef, entropy_coef=ecoef,
+                              grad_scale=1.0, sigma_d=sigma.data_ptr(), actions_d=act.data_ptr(), old_logp_d=old_logp.data_ptr(),
+                              advantages_d=adv.data_ptr(), dmu_d=dmu2.data_ptr(), dsigma_d=dsg2.data_ptr())
+    else:
+        hl = _lib.ImxHeadLoss(mode=2, sigma_stride=0, use_clipped_value_loss=1, clip_param=clip, value_loss_coef=vcoef, entropy_coef=ecoef,
+                              grad_scale=1.0, returns_d=ret.data_ptr(), old_values_d=old_v.data_ptr(), dvalue_d=dv2.data_ptr())
+    _lib.check(L.imx_mlp_head_fwd_loss(M, K, A, h2.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), 1, 1.0, ctypes.byref(hl), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(h1, h2)
+    if A > 1:
+        assert torch.equal(dmu1, dmu2) and torch.equal(dsg1, dsg2) and bool(torch.isfinite(dmu2).all())
+    else:
+        assert torch.equal(dv1, dv2)
+    bad = _lib.ImxHeadLoss(mode=2, returns_d=ret.data_ptr(), dvalue_d=dv2.data_ptr(), use_clipped_value_loss=0)
+    if A > 1:
+        with pytest.raises(_lib.ImxError):  # the value head has one output
+            _lib.check(L.imx_mlp_head_fwd_loss(M, K, A, h2.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), 0, 1.0, ctypes.byref(bad), st))
