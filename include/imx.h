@@ -194,6 +194,9 @@ typedef struct imx_buffers {
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char* imx_version(void);
+/* sizeof of an ABI struct as this library was compiled (which: 0 imx_state_t, 1 imx_buffers_t, 2 imx_head_loss_t), 0 for an unknown index:
+ * a binding checks its own layout against it at load time. */
+size_t imx_struct_size(int which);
 const char* imx_last_error(void);
 int imx_device_count(void);
 

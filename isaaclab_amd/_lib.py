@@ -50,6 +50,7 @@ _SIGNATURES = {
     "imx_device_count": (c_int, []),
     "imx_plan_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "imx_plan_destroy": (None, [c_void_p]),
+    "imx_struct_size": (c_size_t, [c_int]),
     "imx_plan_scratch_bytes": (c_size_t, [c_void_p, c_int64]),
     "imx_plan_obs_dim": (c_int, [c_void_p]),
     "imx_action_process": (c_int, [c_void_p, c_int64, c_void_p, c_float, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
@@ -140,6 +141,10 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    for which, cls in enumerate((ImxState, ImxBuffers, ImxHeadLoss)):  # the binding's struct layouts against the library's
+        if int(L.imx_struct_size(which)) != ctypes.sizeof(cls):
+            raise ImxError(f"{LIB_PATH}: sizeof({cls.__name__}) is {int(L.imx_struct_size(which))} in the library, {ctypes.sizeof(cls)} in the "
+                           "binding -- rebuild with `python -m isaaclab_amd.build`")
     _lib = L
     return L
 

@@ -22,6 +22,14 @@ void imx_set_error(const char* fmt, ...) {
 
 extern "C" const char* imx_version(void) { return "libimx 0.1 (gfx950; plan v2)"; }
 extern "C" const char* imx_last_error(void) { return g_err.c_str(); }
+extern "C" size_t imx_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(imx_state_t);
+        case 1: return sizeof(imx_buffers_t);
+        case 2: return sizeof(imx_head_loss_t);
+        default: return 0;
+    }
+}
 
 extern "C" int imx_device_count(void) {
     int n = 0;
