@@ -103,6 +103,23 @@ def time_env_path(env, runner_storage_T, iters):
     return N * T * iters / dt, dt / (iters * T)
 
 
+def measured_copy_gbs(device, mib: int = 1024, reps: int = 10) -> float:
+    """Device-to-device stream copy (confirm the vendor HBM figure on the box): read + write bytes per second of a
+    float4 copy of ``mib`` MiB, HIP events on the current stream."""
+    n = mib * 1024 * 1024 // 4
+    src = torch.empty(n, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize(device)
+    return 2.0 * 4.0 * n * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def time_obs_kernel(env, launches=200):
     """Average duration of k_obs from HIP events on the stream it is launched on (torch's current stream)."""
     dev = env.device
@@ -331,7 +348,8 @@ def main():
             traffic = json.load(open(tf)).get("k_obs_bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "kernel": "k_obs<false> (observation assembly + fused height-scanner ray-cast)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6}
+                           "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6,
+                           "peak_measured_copy": measured_copy_gbs(device)}  # GB/s of a 1 GiB device-to-device copy on this box
         # the same kernel at 16x the batch (65 536 envs): what the layout reaches once launch latency is amortised
         if os.environ.get("IMX_BENCH_LARGE_N", "1") == "1" and not args.no_large_n and args.task == TASK:
             try:
