@@ -660,3 +660,58 @@ def test_head_forward_with_fused_loss_gradient_equals_two_launches(libimx, A):
     if A > 1:
         with pytest.raises(_lib.ImxError):  # the value head has one output
             _lib.check(L.imx_mlp_head_fwd_loss(M, K, A, h2.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), 0, 1.0, ctypes.byref(bad), st))
+
+
+@pytest.mark.gpu
+def test_update_through_the_rccl_path_single_rank(libimx):
+    """The multi-GPU branch of PPO.update (bucket all-reduce over RCCL + division by the world size, eager update) on a single-rank
+    nccl group: one rank's mean is its own gradient, so parameters must equal the non-distributed update bit for bit."""
+    import copy
+    import socket
+
+    import torch.distributed as dist
+
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    T, N, D, A = 8, 64, 48, 12
+    torch.manual_seed(5)
+    pol0 = ActorCritic(D, D, A, actor_hidden_dims=[128, 64], critic_hidden_dims=[128, 64], init_noise_std=1.0)
+    kw = dict(num_learning_epochs=2, num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
+              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    g = torch.Generator().manual_seed(9)
+    obs, noise = torch.randn(T, N, D, generator=g), torch.randn(T, N, A, generator=g)
+    ret_noise, adv = 0.3 * torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
+
+    def run(multi):
+        alg = PPO(copy.deepcopy(pol0), device="cuda:0", multi_gpu_cfg={"global_rank": 0, "local_rank": 0, "world_size": 1} if multi else None, **kw)
+        alg.init_storage("rl", N, T, (D,), (0,), (A,))
+        torch.manual_seed(77)
+        for it in range(2):
+            st = alg.storage
+            st.observations.copy_(obs + 0.1 * it)
+            with torch.no_grad():
+                mu = alg.policy.actor(st.observations.flatten(0, 1)).view(T, N, A)
+                val = alg.policy.critic(st.observations.flatten(0, 1)).view(T, N, 1)
+            sigma = alg.policy.std.detach().expand(T, N, A).contiguous()
+            act = mu + sigma * noise.cuda()
+            st.mu.copy_(mu); st.sigma.copy_(sigma); st.actions.copy_(act); st.values.copy_(val)
+            st.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+            st.returns.copy_(val + ret_noise.cuda())
+            st.advantages.copy_(adv)
+            st.step = T
+            alg.update()
+        torch.cuda.synchronize()
+        return alg.bucket.flat.clone(), alg.learning_rate
+
+    ref, lr_ref = run(False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got, lr = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert lr == lr_ref and torch.equal(got, ref)
