@@ -480,9 +480,24 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
 #pragma unroll
         for (int q = 0; q < 16; ++q) wacc[b][q] = 0.0f;
     }
+    // the 32 x A slab of dY of a row block is contiguous in memory: the workgroup copies it to LDS once (coalesced, double-buffered,
+    // one barrier per row block) and the 16*AB + ceil(A/2) operand reads below come from there instead of 51 strided global loads
+    // per wave at A = 37.  Row pitch odd: the column reads of the dX phase (lane = row) spread over the banks.
+    __shared__ float sdy[2][32 * (HEAD_A + 1)];
+    const int P = A | 1;
     const int64_t nblk = (M + 31) / 32;
-    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x) {
+    int buf = 0;
+    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x, buf ^= 1) {
         const int64_t m0 = rb * 32;
+        {
+            const int64_t base = m0 * A, lim = M * (int64_t)A;
+            for (int e = threadIdx.x; e < 32 * A; e += blockDim.x) {
+                const int row = e / A, col = e - row * A;
+                sdy[buf][row * P + col] = base + e < lim ? dY[base + e] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const float* __restrict__ ty = sdy[buf];
         float hv[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -496,8 +511,7 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
         for (int s = 0; s < AB * 16; ++s)
             if (s < steps) {
                 const int o = 2 * s + half;
-                const int64_t row = m0 + r;
-                const float av = (row < M && o < A) ? dY[row * A + o] : 0.0f;
+                const float av = o < A ? ty[r * P + o] : 0.0f;  // rows past M are zero in the slab
                 dx = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[s], dx, 0, 0, 0);
             }
         if (m0 + 32 <= M) {  // interior block: unconditional stores
@@ -516,11 +530,10 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int64_t row = m0 + acc_row(q, half);
 #pragma unroll
             for (int b = 0; b < AB; ++b) {
                 const int o = 32 * b + r;
-                const float av = (row < M && o < A) ? dY[row * A + o] : 0.0f;
+                const float av = o < A ? ty[acc_row(q, half) * P + o] : 0.0f;
                 wacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[q], wacc[b], 0, 0, 0);
                 dbacc[b] += av;
             }
