@@ -262,15 +262,23 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libimx has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # IMX_REHEARSE_ONE_GPU=1 (with torchrun --nproc-per-node 2): every rank on cuda:0 and a gloo group -- the whole multi-rank
+    # flow of this file (barriers, max-over-ranks timing, rank-0 line, tear-down) and of PPO.update on a one-GPU box; RCCL itself is
+    # exercised by IMX_FORCE_DIST=1 (single-rank nccl group) and tests/test_kernels_gpu.py
+    rehearsal = os.environ.get("IMX_REHEARSE_ONE_GPU") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     force_dist = os.environ.get("IMX_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
 

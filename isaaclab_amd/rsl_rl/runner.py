@@ -79,13 +79,16 @@ class OnPolicyRunner:
         self.gpu_global_rank = int(os.getenv("RANK", "0"))
         self.multi_gpu_cfg = {"global_rank": self.gpu_global_rank, "local_rank": self.gpu_local_rank,
                               "world_size": self.gpu_world_size}
-        if self.device.type == "cuda" and self.device.index is not None and self.device.index != self.gpu_local_rank:
+        # IMX_REHEARSE_ONE_GPU=1: every rank on cuda:0 (with a gloo group): the multi-rank logic on a one-GPU box, everything but RCCL
+        rehearsal = os.getenv("IMX_REHEARSE_ONE_GPU") == "1"
+        if (self.device.type == "cuda" and self.device.index is not None and self.device.index != self.gpu_local_rank
+                and not rehearsal):
             raise ValueError(f"Device '{self.device}' does not match expected device for local rank '{self.gpu_local_rank}'.")
         if not dist.is_initialized():
-            dist.init_process_group(backend="nccl" if self.device.type == "cuda" else "gloo", rank=self.gpu_global_rank,
-                                    world_size=self.gpu_world_size)
+            dist.init_process_group(backend="nccl" if self.device.type == "cuda" and not rehearsal else "gloo",
+                                    rank=self.gpu_global_rank, world_size=self.gpu_world_size)
         if self.device.type == "cuda":
-            torch.cuda.set_device(self.gpu_local_rank)
+            torch.cuda.set_device(0 if rehearsal else self.gpu_local_rank)
 
     # ---- rollout ---------------------------------------------------------------------------------------------------
     def _fusable(self) -> bool:
