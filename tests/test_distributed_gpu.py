@@ -1,0 +1,75 @@
+"""Data-parallel PPO.update with two ranks on the one GPU of the test box (gloo group, both ranks on cuda:0): every kernel of the
+update is the HIP path, only the transport differs from RCCL.  Replicas must stay identical although their rollouts differ."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import isaaclab_amd  # noqa: F401  (hardware-queue setting before HIP starts)
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, N, D, A = 8, 64, 48, 12
+    torch.manual_seed(100 + rank)  # different initial weights per rank: broadcast_parameters must fix that
+    pol = ActorCritic(D, D, A, actor_hidden_dims=[128, 64], critic_hidden_dims=[128, 64], init_noise_std=1.0)
+    alg = PPO(pol, device="cuda:0", multi_gpu_cfg={"global_rank": rank, "local_rank": rank, "world_size": world}, num_learning_epochs=2,
+              num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005, max_grad_norm=1.0,
+              clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    alg.init_storage("rl", N, T, (D,), (0,), (A,))
+    alg.broadcast_parameters()
+    g = torch.Generator().manual_seed(500 + rank)  # each rank its own rollout
+    for it in range(2):
+        st = alg.storage
+        st.observations.copy_(torch.randn(T, N, D, generator=g))
+        with torch.no_grad():
+            mu = alg.policy.actor(st.observations.flatten(0, 1)).view(T, N, A)
+            val = alg.policy.critic(st.observations.flatten(0, 1)).view(T, N, 1)
+        sigma = alg.policy.std.detach().expand(T, N, A).contiguous()
+        act = mu + sigma * torch.randn(T, N, A, generator=g).cuda()
+        st.mu.copy_(mu); st.sigma.copy_(sigma); st.actions.copy_(act); st.values.copy_(val)
+        st.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+        st.returns.copy_(val + 0.3 * torch.randn(T, N, 1, generator=g).cuda())
+        st.advantages.copy_(torch.randn(T, N, 1, generator=g))
+        st.step = T
+        alg.update()
+    torch.cuda.synchronize()
+    flat = alg.bucket.flat.detach().cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    lrs = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(lrs, torch.tensor([alg.learning_rate]))
+    ok = all(torch.equal(x, gathered[0]) for x in gathered) and all(float(x) == float(lrs[0]) for x in lrs) and bool(torch.isfinite(flat).all())
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_keep_identical_replicas():
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(0) is True and out.get(1) is True
