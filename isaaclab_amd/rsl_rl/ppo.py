@@ -75,8 +75,12 @@ def fused_ppo_loss(mu, sigma, actions, old_logp, old_mu, old_sigma, adv, ret, va
 class FlatParams:
     """Re-homes every parameter (and gradient) of ``module`` into one contiguous fp32 bucket."""
 
-    def __init__(self, module: nn.Module, extra_slots: int = 1):
+    def __init__(self, module: nn.Module, extra_slots: int = 1, first=()):
+        """``first``: parameters to lay out first, in this order (e.g. the two first-layer weights next to each other so that
+        they can be used as one stacked matrix); the rest follows in ``module.parameters()`` order."""
         params = [p for p in module.parameters() if p.requires_grad]
+        head = [p for p in first if any(p is q for q in params)]
+        params = head + [p for p in params if not any(p is q for q in head)]
         self.numel = sum(p.numel() for p in params)
         dev = params[0].device
         self.flat = torch.zeros(self.numel, device=dev)
@@ -222,15 +226,20 @@ class DeferredReductions:
             pass
 
 
-def mlp_forward(layers, x, out=None, head_loss=None):
+def mlp_forward(layers, x, out=None, head_loss=None, first=None):
     """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
     the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given).  ``head_loss`` = {"loss": ImxHeadLoss}:
     when the LAST layer goes through the head kernel, the loss gradient is computed in the same launch
-    (``imx_mlp_head_fwd_loss``) and ``head_loss["applied"]`` is set."""
+    (``imx_mlp_head_fwd_loss``) and ``head_loss["applied"]`` is set.  ``first``: the (already activated) output of layer 0 when
+    it was computed elsewhere (actor and critic first layers as one stacked GEMM): the walk starts at layer 1."""
     saved = [x]
     h = x
     pending_elu = None  # ELU of the last hidden layer is applied by the head kernel on its way in (in place)
     for li, (lin, act) in enumerate(layers):
+        if li == 0 and first is not None:
+            h = first
+            saved.append(h)
+            continue
         if act is None and _is_head(lin, h):
             if out is not None and li == len(layers) - 1:
                 z = out
@@ -352,7 +361,20 @@ class PPO:
         else:
             self.gpu_global_rank, self.gpu_world_size = 0, 1
         self.policy = policy.to(self.device)
-        self.bucket = FlatParams(self.policy, extra_slots=8)  # trailing slots = the 8 loss scalars (KL among them)
+        # actor and critic first layers side by side in the bucket: when both read the same observations they are ONE stacked GEMM
+        pair = self._first_layer_pair()
+        self.bucket = FlatParams(self.policy, extra_slots=8,  # trailing slots = the 8 loss scalars (KL among them)
+                                 first=() if pair is None else (pair[0].weight, pair[1].weight, pair[0].bias, pair[1].bias))
+        self._joint0 = None
+        if pair is not None:
+            la, lc, _alpha = pair
+            H, K = la.out_features, la.in_features
+            if (lc.weight.data_ptr() == la.weight.data_ptr() + 4 * H * K and lc.bias.data_ptr() == la.bias.data_ptr() + 4 * H
+                    and la.weight.is_contiguous() and lc.weight.is_contiguous()):
+                w0 = self.bucket.flat[:2 * H * K].view(2 * H, K)
+                b0 = self.bucket.flat[2 * H * K:2 * H * K + 2 * H]
+                if w0.data_ptr() == la.weight.data_ptr() and b0.data_ptr() == la.bias.data_ptr():
+                    self._joint0 = (w0, b0, H, float(pair[2]))
         self.storage: RolloutStorage | None = None
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
@@ -388,6 +410,18 @@ class PPO:
     @property
     def learning_rate(self) -> float:
         return float(self._adam[0].item())
+
+    def _first_layer_pair(self):
+        """(actor Linear 0, critic Linear 0, ELU alpha) when the two first layers have the same shape and an ELU behind them."""
+        try:
+            (la, aa), (lc, ac) = _mlp_layers(self.policy.actor)[0], _mlp_layers(self.policy.critic)[0]
+        except (IndexError, AttributeError, TypeError):
+            return None
+        if len(_mlp_layers(self.policy.actor)) < 2 or len(_mlp_layers(self.policy.critic)) < 2:
+            return None
+        same = (la.in_features == lc.in_features and la.out_features == lc.out_features and la.bias is not None and lc.bias is not None
+                and isinstance(aa, nn.ELU) and isinstance(ac, nn.ELU) and aa.alpha == ac.alpha)
+        return (la, lc, aa.alpha) if same else None
 
     # ---- storage / rollout -----------------------------------------------------------------------------------
     def init_storage(self, training_type, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, actions_shape):
@@ -474,7 +508,7 @@ class PPO:
                                                entropy_coef=ecoef, grad_scale=1.0, sigma_d=sigma.data_ptr(), actions_d=actions.data_ptr(),
                                                old_logp_d=old_logp.data_ptr(), advantages_d=advantages.data_ptr(),
                                                dmu_d=ws["dmu"].data_ptr(), dsigma_d=ws["dsigma"].data_ptr())}
-            mu, saved_a = mlp_forward(self._actor_layers, obs, head_loss=hl)
+            mu, saved_a = mlp_forward(self._actor_layers, obs, head_loss=hl, first=first_a)
             if sigma is None:
                 sigma = torch.exp(pol.log_std).expand_as(mu).contiguous()
             if hl is None or not hl.get("applied"):
@@ -487,7 +521,7 @@ class PPO:
             hl = {"loss": _lib.ImxHeadLoss(mode=2, sigma_stride=0, use_clipped_value_loss=vclip, clip_param=clipf, value_loss_coef=vcoef,
                                            entropy_coef=ecoef, grad_scale=1.0, returns_d=returns.data_ptr(),
                                            old_values_d=target_values.data_ptr(), dvalue_d=ws["dvalue"].data_ptr())}
-            value, saved_c = mlp_forward(self._critic_layers, critic_obs, head_loss=hl)
+            value, saved_c = mlp_forward(self._critic_layers, critic_obs, head_loss=hl, first=first_c)
             if not hl.get("applied"):
                 check(L.imx_ppo_loss_bwd(M, A, None, None, sstride, None, None, None, returns.data_ptr(), value.data_ptr(),
                                          target_values.data_ptr(), clipf, vclip, vcoef, ecoef, 1.0, None, None, ws["dvalue"].data_ptr(), st))
@@ -511,6 +545,13 @@ class PPO:
         # The policy gradient needs only mu, the value gradient only the critic's output: actor and critic run
         # forward -> loss gradient -> backward on two streams and meet once, at the end of the minibatch.  The loss
         # VALUES (logging, KL for the adaptive LR) need both heads and run on a third stream beside the backward GEMMs.
+        # Same observations for both networks (no privileged group) and same first-layer shape: ONE stacked GEMM [W_a; W_c] and one
+        # ELU over (M, 2H) -- the observations are read once, one launch each instead of two; the halves are strided views
+        first_a = first_c = z0 = None
+        if self._joint0 is not None and critic_obs.data_ptr() == obs.data_ptr() and critic_obs.shape == obs.shape:
+            w0, b0, H0, alpha0 = self._joint0
+            z0 = F.elu(torch.addmm(b0, obs, w0.t()), alpha=alpha0, inplace=True)
+            first_a, first_c = z0[:, :H0], z0[:, H0:]
         side = self._side_stream()
         main = torch.cuda.current_stream(self.device)
         if side is not None:
@@ -536,6 +577,8 @@ class PPO:
             mu.record_stream(aux)
             value.record_stream(aux)
             value.record_stream(main)
+            if z0 is not None:
+                z0.record_stream(side)
         else:
             mu, saved_a = actor_pass(stream)
             value, saved_c = critic_pass(stream)

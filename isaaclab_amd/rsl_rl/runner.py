@@ -49,8 +49,12 @@ class OnPolicyRunner:
         else:
             self.obs_normalizer = torch.nn.Identity().to(self.device)
             self.privileged_obs_normalizer = torch.nn.Identity().to(self.device)
-        self.alg.init_storage("rl", self.env.num_envs, self.num_steps_per_env, [num_obs], [num_privileged_obs],
-                              [self.env.num_actions])
+        # Without a privileged ("critic") observation group the critic reads the policy observations: no second (T, N, D) buffer is
+        # kept -- upstream stores a copy; here the minibatch hands the SAME rows to both networks (half the gather traffic, and the two
+        # first layers become one stacked GEMM).  A buffer that the fused rollout does not fill must not exist: it would feed the
+        # critic zeros.
+        priv_shape = [num_privileged_obs] if self.privileged_obs_type is not None else [0]
+        self.alg.init_storage("rl", self.env.num_envs, self.num_steps_per_env, [num_obs], priv_shape, [self.env.num_actions])
         self.disable_logs = self.is_distributed and self.gpu_global_rank != 0
         self.log_dir = log_dir
         self.current_learning_iteration = 0

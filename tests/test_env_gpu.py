@@ -313,6 +313,10 @@ def test_fused_rollout_storage_is_self_consistent(use_graph):
         assert_close(runner.last_obs, env.unwrapped._obs, 0, "last obs")
     assert st.dones.sum() > 0 and set(st.dones.unique().tolist()) <= {0, 1}
     assert torch.isfinite(st.rewards).all() and float(st.rewards.abs().sum()) > 0
+    # no privileged group: the critic's minibatch IS the policy's (no second buffer that the fused rollout would leave unfilled)
+    assert st.privileged_observations is None
+    batch = next(iter(st.mini_batch_generator(4, 1)))
+    assert batch[1] is batch[0] and float(batch[0].abs().sum()) > 0
 
 
 @pytest.mark.gpu
