@@ -411,6 +411,30 @@ class PPO:
     def learning_rate(self) -> float:
         return float(self._adam[0].item())
 
+    def optimizer_state_dict(self) -> dict:
+        """Adam moments PER PARAMETER NAME (independent of where a parameter sits in the flat bucket) + the 8 device-side scalars."""
+        base, out = self.bucket.flat.data_ptr(), {"exp_avg": {}, "exp_avg_sq": {}, "adam_state": self._adam.clone()}
+        for name, p in self.policy.named_parameters():
+            if not p.requires_grad:
+                continue
+            off = (p.data_ptr() - base) // 4
+            out["exp_avg"][name] = self.bucket.exp_avg[off:off + p.numel()].view_as(p).clone()
+            out["exp_avg_sq"][name] = self.bucket.exp_avg_sq[off:off + p.numel()].view_as(p).clone()
+        return out
+
+    def load_optimizer_state_dict(self, o: dict) -> None:
+        base = self.bucket.flat.data_ptr()
+        if isinstance(o["exp_avg"], dict):
+            for name, p in self.policy.named_parameters():
+                if p.requires_grad and name in o["exp_avg"]:
+                    off = (p.data_ptr() - base) // 4
+                    self.bucket.exp_avg[off:off + p.numel()].copy_(o["exp_avg"][name].reshape(-1))
+                    self.bucket.exp_avg_sq[off:off + p.numel()].copy_(o["exp_avg_sq"][name].reshape(-1))
+        else:  # flat tensors in bucket order (checkpoints written before the moments were keyed by name)
+            self.bucket.exp_avg.copy_(o["exp_avg"])
+            self.bucket.exp_avg_sq.copy_(o["exp_avg_sq"])
+        self._adam.copy_(o["adam_state"])
+
     def _first_layer_pair(self):
         """(actor Linear 0, critic Linear 0, ELU alpha) when the two first layers have the same shape and an ELU behind them."""
         try:

@@ -250,8 +250,7 @@ class OnPolicyRunner:
     def save(self, path: str, infos=None):
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         torch.save({"model_state_dict": self.alg.policy.state_dict(),
-                    "optimizer_state_dict": {"exp_avg": self.alg.bucket.exp_avg, "exp_avg_sq": self.alg.bucket.exp_avg_sq,
-                                             "adam_state": self.alg._adam},
+                    "optimizer_state_dict": self.alg.optimizer_state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)
 
     def load(self, path: str, load_optimizer: bool = True):
@@ -260,10 +259,7 @@ class OnPolicyRunner:
             for k, v in d["model_state_dict"].items():
                 self.alg.policy.state_dict()[k].copy_(v)  # in place: parameters stay views of the flat bucket
         if load_optimizer and "optimizer_state_dict" in d:
-            o = d["optimizer_state_dict"]
-            self.alg.bucket.exp_avg.copy_(o["exp_avg"])
-            self.alg.bucket.exp_avg_sq.copy_(o["exp_avg_sq"])
-            self.alg._adam.copy_(o["adam_state"])
+            self.alg.load_optimizer_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d.get("iter", 0)
         return d.get("infos")
 

@@ -270,9 +270,15 @@ def test_runner_learn_modes(mode, tmp_path):
     ck = str(tmp_path / "model.pt")
     runner.save(ck)
     before = runner.alg.bucket.flat.clone()
+    m_before, v_before = runner.alg.bucket.exp_avg.clone(), runner.alg.bucket.exp_avg_sq.clone()
+    assert float(m_before.abs().sum()) > 0
     runner.alg.bucket.flat.zero_()
+    runner.alg.bucket.exp_avg.zero_()
+    runner.alg.bucket.exp_avg_sq.zero_()
     runner.load(ck)
     assert torch.equal(before, runner.alg.bucket.flat)
+    # Adam moments travel keyed by parameter name (independent of the bucket layout) and land where they came from
+    assert torch.equal(m_before, runner.alg.bucket.exp_avg) and torch.equal(v_before, runner.alg.bucket.exp_avg_sq)
     policy = runner.get_inference_policy(device="cuda:0")
     a = policy(env.get_observations()[0])
     assert a.shape == (64, 12) and torch.isfinite(a).all()
