@@ -299,6 +299,10 @@ def main():
             runner.alg.compute_returns(runner.last_obs)
         runner.alg.update()
 
+    # untimed priming, whatever --warmup says: the rollout graph is captured in the first iteration and the update decides between
+    # eager issue and hipGraph replay over its first five calls (PPO.update) -- neither may fall into the timed region
+    for _ in range(5):
+        iteration()
     for _ in range(args.warmup):
         iteration()
     if world > 1:
