@@ -209,11 +209,12 @@ def time_mlp_dw(alg, M: int, device, launches: int = 30) -> dict:
         if N <= HEAD_MAX_OUT:
             continue
         dY = torch.randn(M, N, device=device)
-        X = torch.randn(M, K, device=device)
+        ldx = (K + 3) // 4 * 4  # rows on 16-byte boundaries, as the minibatch buffers of the update keep them (storage.py)
+        X = torch.randn(M, ldx, device=device)
         dW, db = torch.empty(N, K, device=device), torch.empty(N, device=device)
         nb = int(L.imx_mlp_scratch_bytes(M, N, K))
         scr = torch.empty(nb, dtype=torch.uint8, device=device)
-        args = (M, N, K, dY.data_ptr(), N, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st)
+        args = (M, N, K, dY.data_ptr(), N, X.data_ptr(), ldx, dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st)
         for _ in range(3):
             check(L.imx_mlp_dw(*args))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
