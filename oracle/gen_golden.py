@@ -19,9 +19,11 @@ The step emulation follows ``ManagerBasedRLEnv.step`` (isaaclab/envs/manager_bas
 
 from __future__ import annotations
 
+import hashlib
 import json
 import math
 import os
+import re
 import sys
 import types
 
@@ -61,7 +63,9 @@ def _jsonable(x):
         return [_jsonable(v) for v in x]
     if isinstance(x, slice):
         return f"slice({x.start}, {x.stop}, {x.step})"
-    if isinstance(x, (str, int, bool)) or x is None:
+    if isinstance(x, str):  # a path built from a mocked carb setting carries the mock's id(): scrub it (reproducible JSON)
+        return re.sub(r"<_MockModule name='([^']*)' id='\d+'>", r"<mock:\1>", x)
+    if isinstance(x, (int, bool)) or x is None:
         return x
     if isinstance(x, float):
         if math.isinf(x) or math.isnan(x):
@@ -71,7 +75,7 @@ def _jsonable(x):
         return x.item()
     if isinstance(x, torch.Tensor):
         return x.tolist()
-    return str(x)
+    return _jsonable(str(x))
 
 
 def dump_cfg(task: str, env_cfg, agent_cfg, robot: RobotSpec):
@@ -252,6 +256,18 @@ def ref_height_scanner(scanner_cfg, feed: StateFeed, mesh):
 
 
 # --------------------------------------------------------------------------- one task
+def mesh_sha256(vertices, triangles) -> str:
+    """Hash of the terrain mesh a fixture was generated on (tests/test_oracle_golden.py re-derives it from the terrain
+    generator at HEAD, so that a change of ``make_rough_terrain`` cannot strand a committed fixture unnoticed)."""
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(vertices, np.float32).tobytes())
+    h.update(np.ascontiguousarray(triangles, np.uint32).tobytes())
+    return h.hexdigest()
+
+
+ROUGH_TERRAIN_ARGS = dict(num_rows=2, num_cols=3, tile=4.0, border=3.0, seed=11)  # the small terrain of the rough fixtures
+
+
 def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int, seed: int, mesh=None, extent=None):
     torch.manual_seed(seed)
     dump_cfg(task, env_cfg, agent_cfg, robot)
@@ -277,6 +293,8 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
     if has_scan:
         put("mesh/vertices", mesh[0])
         put("mesh/triangles", mesh[1])
+        meta["mesh_sha256"] = mesh_sha256(mesh[0], mesh[1])
+        meta["terrain_args"] = ROUGH_TERRAIN_ARGS
 
     # uniform samples consumed by uniform_noise (observation_manager.py:313 -> noise_model.py:62): recorded so the
     # HIP path can be fed the same draws (torch's CPU RNG stream cannot be reproduced in-kernel).
@@ -442,7 +460,7 @@ def main():
     if not only:
         math_fixture()
         mesh_fixture()
-    verts, tris, ext = make_rough_terrain(2, 3, tile=4.0, border=3.0, seed=11)
+    verts, tris, ext = make_rough_terrain(**ROUGH_TERRAIN_ARGS)
     mesh = (verts, tris)
     if want("Isaac-Cartpole-v0"):
         run_task("Isaac-Cartpole-v0", CartpoleEnvCfg(), CartpolePPORunnerCfg(), CARTPOLE, N=64, steps=3, seed=101)

@@ -104,3 +104,27 @@ def test_events_oracle_matches_reference():
     assert torch.equal(lv, t("curr/levels_out"))
     assert torch.equal(og, t("curr/env_origins_out"))
     assert abs(float(mean) - float(z["curr/mean_level"])) < 1e-6
+
+
+@pytest.mark.parametrize("task", [t for t in TASKS if "Rough" in t])
+def test_rough_fixture_mesh_is_the_generator_mesh_at_head(task):
+    """A fixture with a terrain stores the sha256 of the mesh it was generated on (oracle/gen_golden.py::mesh_sha256).  The mesh in
+    the .npz must carry that hash, and so must the terrain generator at HEAD with the recorded arguments: a change to
+    ``make_rough_terrain`` that is not followed by regenerating the fixtures fails here instead of stranding them."""
+    import hashlib
+
+    from isaaclab_amd.terrain import make_rough_terrain
+
+    def sha(v, t):
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(v, np.float32).tobytes())
+        h.update(np.ascontiguousarray(t, np.uint32).tobytes())
+        return h.hexdigest()
+
+    g = Golden(task)
+    v, t = g.mesh()
+    assert sha(v, t) == g.meta["mesh_sha256"]
+    v2, t2, _ = make_rough_terrain(**g.meta["terrain_args"])
+    assert sha(v2, t2) == g.meta["mesh_sha256"], "terrain generator changed: re-run oracle/gen_golden.py for the rough tasks"
+    # the small terrain must contain box-primitive (general) cells as well as height-field (lattice) cells
+    assert len(t) < 2 * 81 * 81 * 6, "expected a mixed mesh, not six all-height-field tiles"
