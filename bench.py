@@ -2,7 +2,10 @@
 """Headline benchmark: env-steps/s of the RSL-RL PPO loop on Isaac-Velocity-Rough-Anymal-C-v0, 4096 envs per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1 without a launcher: this process starts ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...``
+     as a CHILD -- it never touches the GPU itself --, relays rank 0's JSON line and exits with the child's code; under torchrun
+     (WORLD_SIZE set) it is a rank.  Same contract as the reference's ``python -m torch.distributed.run --nnodes=1 --nproc_per_node=N
+     scripts/reinforcement_learning/rsl_rl/train.py --distributed``, docs/source/features/multi_gpu.rst:24-29, train.py:118-126.)
 
 One "step" = one PPO iteration on every rank: 24 x (actor-critic act -> imx_action_process -> [state feed advances]
 -> imx_terminations_rewards -> imx_observations(+ray-cast) -> storage) + imx_gae + 5 epochs x 4 minibatches of
@@ -233,6 +236,36 @@ def time_mlp_dw(alg, M: int, device, launches: int = 30) -> dict:
             "flops_per_launch": flops / n, "avg_launch_us": secs / n * 1e6, "samples": M, "per_layer": shapes}
 
 
+def self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: run the N ranks as a child ``torch.distributed.run`` and relay rank 0's
+    line.  This parent has not initialised HIP (importing torch does not) and never does: the children are fresh processes."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:  # rank 0 prints exactly one JSON line on fd 1; anything else a library wrote there goes to stderr
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +281,8 @@ def main():
                     "its name and would skew a rocprofv3 --stats average taken over this command)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before anything touches the GPU
+        raise SystemExit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line (the JSON): native libraries on the GPU box print to fd 1 while the device is
     # initialised (libdrm's "amdgpu.ids: No such file or directory"), so fd 1 points at stderr until the final print
@@ -259,8 +294,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does it itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libimx has no CPU path")
     # IMX_REHEARSE_ONE_GPU=1 (with torchrun --nproc-per-node 2): every rank on cuda:0 and a gloo group -- the whole multi-rank
@@ -323,8 +357,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        rank_ms = [1e3 * float(x.item()) / args.steps for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = args.num_envs * T * world * args.steps / elapsed
@@ -347,6 +385,10 @@ def main():
                    + (" (measured eager %.2f ms, graph %.2f ms)" % runner.alg._update_times_ms if hasattr(runner.alg, "_update_times_ms") else ""),
                    "policy_params": runner.alg.bucket.numel},
         "phase_ms": {"collect_plus_gae": collect_ms, "update": update_ms},
+        "ms_per_step_per_rank": rank_ms,
+        "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "distinct_gpus": 1 if rehearsal else world,
+                        "grad_allreduce_per_iteration": int(runner.alg.num_learning_epochs) * int(runner.alg.num_mini_batches),
+                        "bucket_bytes": 4 * (runner.alg.bucket.numel + 8)} if (world > 1 or force_dist) else None),
     }
     if rank == 0:
         env_rate, env_step_s = time_env_path(env, T, iters=20)

@@ -84,3 +84,22 @@ def test_flat_bucket_allreduce_world2():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     res = dict(q.get() for _ in range(2))
     assert abs(res[0] - 0.019) < 1e-6 and res[0] == res[1]
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_launches_its_own_ranks_and_propagates_failure():
+    """``python bench.py --gpus 2`` outside a launcher must start the two ranks itself (child torch.distributed.run, 127.0.0.1
+    rendezvous) and exit with the child's code.  No GPU here: the ranks refuse to run ('needs an MI355X'), so the parent must print NO
+    result line and return non-zero -- never a fabricated line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the positive path is covered by test_bench_two_rank_rehearsal (gpu)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("needs an MI355X") == 2  # both ranks were started

@@ -73,3 +73,25 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas():
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out.get(0) is True and out.get(1) is True
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal():
+    """The driver's own form ``python bench.py --gpus 2 ...`` on the one GPU of the test box: the parent (which never initialises HIP)
+    starts two ranks through torch.distributed.run, both on cuda:0 over a gloo group (IMX_REHEARSE_ONE_GPU=1), and relays rank 0's
+    single JSON line."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["IMX_REHEARSE_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--num-envs", "512",
+                        "--terrain-tiles", "2", "3", "--no-cpu-baseline", "--no-large-n"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and len(out["ms_per_step_per_rank"]) == 2
+    assert out["collective"]["ranks"] == 2 and out["collective"]["backend"] == "gloo" and out["collective"]["distinct_gpus"] == 1
+    assert out["value"] > 0
