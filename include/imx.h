@@ -28,8 +28,9 @@ typedef void* imx_stream_t;         /* hipStream_t */
 
 /* ---- plan blob: int32 words written by isaaclab_amd/plan.py -------------------------------------------------- */
 #define IMX_MAGIC 0x31584D49 /* "IMX1" */
-#define IMX_PLAN_VERSION 2
-#define IMX_HEADER_WORDS 40
+#define IMX_PLAN_VERSION 3
+#define IMX_HEADER_WORDS 48
+#define IMX_MAX_OBS_GROUPS 4
 #define IMX_REC_WORDS 20
 
 enum imx_header_word {
@@ -39,12 +40,19 @@ enum imx_header_word {
     IMX_H_GRAV_Z, IMX_H_NREW_ALL /* reward terms incl. zero-weight */, IMX_H_RAY_OFF /* R*3 f32 local ray starts */,
     IMX_H_RAYDIR_X /*f32*/, IMX_H_RAYDIR_Y, IMX_H_RAYDIR_Z, IMX_H_RAY_MAXDIST /*f32*/, IMX_H_MAX_EP_LEN_S /*f32*/,
     IMX_H_NEXT_REW, IMX_H_NEXT_TERM, IMX_H_NEXT_OBS, IMX_H_RAY_YAW_ONLY, IMX_H_CMD_DIM,
-    IMX_H_MOD_STATE /* floats of observation-modifier state per env (imx_buffers.mod_state row width) */
+    IMX_H_MOD_STATE /* floats of observation-modifier state per env (imx_buffers.mod_state row width) */,
+    IMX_H_NGROUPS /* observation groups (ObservationManager group loop, observation_manager.py:238-258), 1..IMX_MAX_OBS_GROUPS */,
+    IMX_H_GROUP_OFF /* NGROUPS x 4 words: D_g, enable_corruption, first obs record, number of obs records (IMX_H_D = sum of D_g) */,
+    /* height scanner as a SensorBase (sensors/sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237) */
+    IMX_H_SCAN_PERIOD /* f32 cfg.update_period */, IMX_H_SCAN_DT /* f32 physics dt: SensorBase.update(dt) per physics step */,
+    IMX_H_SCAN_SUBSTEPS /* decimation: update() calls per env step */, IMX_H_SCAN_DRIFT_LO /* f32 cfg.drift_range */,
+    IMX_H_SCAN_DRIFT_HI, IMX_H_SCAN_STATEFUL /* 1: per-env timestamps / drift are kept (imx_buffers.scan_state) */
 };
 
 /* record layout (IMX_REC_WORDS int32/f32 words) */
 enum imx_rec_word {
-    IMX_R_OP = 0, IMX_R_IDS_OFF, IMX_R_NIDS, IMX_R_IDS2_OFF, IMX_R_NIDS2, IMX_R_WEIGHT /*f32; term: time_out flag*/,
+    IMX_R_OP = 0, IMX_R_IDS_OFF, IMX_R_NIDS, IMX_R_IDS2_OFF, IMX_R_NIDS2,
+    IMX_R_WEIGHT /*f32 reward weight (0 = skipped, reward_manager.py:145); termination: time_out flag; observation: group index*/,
     IMX_R_P0 /*f32*/, IMX_R_P1, IMX_R_P2, IMX_R_P3, IMX_R_OUT /* obs: column offset; reward/term: term index */,
     IMX_R_DIM, IMX_R_FLAGS, IMX_R_NOISE_LO /*f32*/, IMX_R_NOISE_HI, IMX_R_CLIP_LO, IMX_R_CLIP_HI, IMX_R_SCALE,
     IMX_R_AUX0, IMX_R_AUX1
@@ -62,6 +70,9 @@ enum imx_rec_word {
  * [op, a, b, soff] (DIGITAL_FILTER: [op, na, nb, soff] followed by na + nb f32 coefficients A then B).  State of element
  * j of a term of width d: mod_state[e][P1 + (soff + k) * d + j]; zeroed for envs reset this step before it is used. */
 #define IMX_F_MODIFIERS 64
+/* a height_scan record that reuses the ray hits of an earlier height_scan record (IMX_R_AUX0 = that record's index), e.g. the
+ * "critic" group scanning the same sensor as "policy": one cast per ray and step, as the reference's lazily updated sensor. */
+#define IMX_F_SCAN_TWIN 128
 enum imx_mod_op {            /* utils/modifiers/modifier.py */
     IMX_M_SCALE = 1,         /* :22-32   a = multiplier */
     IMX_M_BIAS,              /* :49-60   a = value */
@@ -85,7 +96,8 @@ enum imx_term_op {
     IMX_T_JOINT_VEL_MANUAL_LIMIT,  /* :117-124  ids=joints p0=max_velocity */
     IMX_T_JOINT_EFFORT_LIMIT,      /* :127-142  ids=joints (torch.isclose(computed, applied)) */
     IMX_T_TERRAIN_OUT_OF_BOUNDS,   /* isaaclab_tasks .../velocity/mdp/terminations.py:24-52  p0=x_lim p1=y_lim */
-    IMX_T_EXTERNAL                 /* value computed by a Python term; aux0 = column in ext_term */
+    IMX_T_EXTERNAL,                /* value computed by a Python term; aux0 = column in ext_term */
+    IMX_T_COMMAND_RESAMPLE         /* :35-42    p0 = f32(step_dt), nids = num_resamples; state.command_time_left / command_counter */
 };
 
 /* reward ops -- envs/mdp/rewards.py unless noted */
@@ -117,7 +129,8 @@ enum imx_rew_op {
     IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, /* ...:86-96 */
     IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP,  /* ...:99-106 */
     IMX_W_JOINT_POS_TARGET_L2,        /* isaaclab_tasks .../classic/cartpole/mdp/rewards.py:19-26 p0=target */
-    IMX_W_EXTERNAL                    /* aux0 = column in ext_reward */
+    IMX_W_EXTERNAL,                   /* aux0 = column in ext_reward */
+    IMX_W_BODY_LIN_ACC_L2             /* :125-128 ids = asset bodies; state.body_lin_acc_w */
 };
 
 /* observation ops -- envs/mdp/observations.py */
@@ -169,6 +182,9 @@ typedef struct imx_state {
     const float* ext_reward;            /* (N,next_rew) values of Python-evaluated reward terms, or NULL */
     const uint8_t* ext_term;            /* (N,next_term) */
     const float* ext_obs;               /* (N,next_obs) */
+    const float* body_lin_acc_w;        /* (N,NB,3) ArticulationData.body_lin_acc_w */
+    const float* command_time_left;     /* (N)   CommandTerm.time_left (managers/command_manager.py:60-61) */
+    const int64_t* command_counter;     /* (N)   CommandTerm.command_counter */
 } imx_state_t;
 
 /* ---- manager state + outputs (caller-owned, persistent across steps) ------------------------------------------ */
@@ -187,9 +203,17 @@ typedef struct imx_buffers {
     int64_t* reset_env_ids;      /* (N) ascending ids of reset envs; valid prefix = counters[0] */
     int32_t* counters;           /* (8) [0] reset count [1] ticket [2] step counter (RNG) [3..] reserved */
     float* log_out;              /* (NREW_ALL + NTERM + 1) Episode_Reward/<term>, Episode_Termination/<term>, count */
-    float* obs;                  /* (N,D) managers/observation_manager.py:238-335 */
+    float* obs;                  /* (N,D_0) first observation group; managers/observation_manager.py:238-335 */
     void* scratch;               /* imx_plan_scratch_bytes(plan, N) bytes */
     float* mod_state;            /* (N, IMX_H_MOD_STATE) DigitalFilter / Integrator state; NULL when the plan has none */
+    float* obs_extra1;           /* (N,D_1) second observation group (e.g. "critic"); NULL when the plan has one group */
+    float* obs_extra2;           /* (N,D_2) */
+    float* obs_extra3;           /* (N,D_3) */
+    float* scan_state;           /* (2,N,8) double-buffered [timestamp, timestamp_last_update, drift xyz, data.pos_w z, outdated, -]
+                                    of the height scanner; required when IMX_H_SCAN_STATEFUL; the caller starts it with zeros and
+                                    outdated = 1 (sensors start outdated, sensor_base.py _initialize_impl) */
+    float* scan_hit_z;           /* (N,R) data.ray_hits_w[..., 2] kept for envs whose sensor is not outdated at the next step */
+    const float* scan_drift_feed;/* optional (N,3): drift values taken at a sensor reset instead of the in-kernel draw (parity runs) */
 } imx_buffers_t;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -203,6 +227,11 @@ int imx_device_count(void);
 /* term compiler output -> device tables.  Replaces ManagerBase._prepare_terms (managers/manager_base.py:160). */
 int imx_plan_create(const int32_t* blob, size_t nwords, imx_plan_t** out);
 void imx_plan_destroy(imx_plan_t* plan);
+/* RewardManager.set_term_cfg / TerminationManager.set_term_cfg (managers/reward_manager.py:163-176,
+ * managers/termination_manager.py:207-220; used by envs/mdp/curriculums.py:20-37 modify_reward_weight): replace the tables of
+ * `plan` IN PLACE by a recompiled blob of the same shape (same term counts, widths and table sizes -- a changed weight, threshold,
+ * id list of equal length ...).  The copy is enqueued on `stream`; graphs that captured launches on `plan` stay valid. */
+int imx_plan_update(imx_plan_t* plan, const int32_t* blob, size_t nwords, imx_stream_t stream);
 size_t imx_plan_scratch_bytes(const imx_plan_t* plan, int64_t num_envs);
 int imx_plan_obs_dim(const imx_plan_t* plan);
 
@@ -226,7 +255,9 @@ int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx
  * Terms with ObservationTermCfg.history_length > 0 keep their flattened (H, d) window (oldest first; CircularBuffer,
  * utils/buffers/circular_buffer.py:107-135) in the obs row itself: envs flagged in buf->reset_buf -- or every env when bit 1
  * of enable_corruption is set (env.reset()) -- take the new value in every slot, the others slide by one.  * enable_corruption bit 2 (value 4): the per-env frame table (root-frame vectors, scanner yaw) is current -- imx_terminations_rewards was
- * called with root_pos_w on the SAME state tensors since they last changed and wrote it -- so the k_frame launch is skipped. */
+ * called with root_pos_w on the SAME state tensors since they last changed and wrote it -- so the k_frame launch is skipped.
+ * enable_corruption bit 3 (value 8): with a stateful height scanner, keep the hit heights of EVERY env in scan_hit_z, not only of
+ * those whose fp32 timestamps say they will skip the next update (a caller that is about to overwrite the timestamps in scan_state). */
 int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
                      const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
                      float* ray_hits_out_d, imx_stream_t stream);

@@ -16,10 +16,12 @@ STATE_FIELDS = (
     "applied_torque", "computed_torque", "default_joint_pos", "default_joint_vel", "soft_joint_pos_limits",
     "soft_joint_vel_limits", "body_lin_vel_w", "command", "net_forces_w_history", "last_air_time",
     "current_air_time", "current_contact_time", "env_origins", "ext_reward", "ext_term", "ext_obs",
+    "body_lin_acc_w", "command_time_left", "command_counter",
 )
 BUFFER_FIELDS = (
     "episode_length_buf", "action", "prev_action", "processed_action", "reward_buf", "episode_sums", "step_reward",
     "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch", "mod_state",
+    "obs_extra1", "obs_extra2", "obs_extra3", "scan_state", "scan_hit_z", "scan_drift_feed",
 )
 
 
@@ -50,6 +52,7 @@ _SIGNATURES = {
     "imx_device_count": (c_int, []),
     "imx_plan_create": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "imx_plan_destroy": (None, [c_void_p]),
+    "imx_plan_update": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "imx_struct_size": (c_size_t, [c_int]),
     "imx_plan_scratch_bytes": (c_size_t, [c_void_p, c_int64]),
     "imx_plan_obs_dim": (c_int, [c_void_p]),

@@ -45,6 +45,11 @@ struct imx_plan {
     int DC = 0;                   // computed observation columns (= D unless a term keeps a history window)
     int xmod_off = 0;             // DC x 4 words: [program offset, program words, state offset of this column, term width]
     int MS = 0;                   // floats of modifier state per env
+    int DX = 0;                   // xcol entries: DC scheduled columns + twin height-scan columns
+    int ngroups = 1;              // observation groups; group g = columns [gbase[g], gbase[g] + gD[g]) of the D-wide column space
+    int gD[IMX_MAX_OBS_GROUPS] = {0, 0, 0, 0}, gbase[IMX_MAX_OBS_GROUPS] = {0, 0, 0, 0};
+    bool gcorrupt[IMX_MAX_OBS_GROUPS] = {false, false, false, false};
+    bool scan_stateful = false;
     bool needs_mesh = false;
 };
 
@@ -59,6 +64,9 @@ struct PlanView {
     float gx, gy, gz;
     float rdx, rdy, rdz, ray_max_dist;
     int ray_yaw_only;
+    int ngroups, gD[IMX_MAX_OBS_GROUPS], gbase[IMX_MAX_OBS_GROUPS], gcorrupt;
+    int scan_stateful, scan_substeps;
+    float scan_period, scan_dt, drift_lo, drift_hi;
 };
 PlanView imx_plan_view(const imx_plan* p);
 

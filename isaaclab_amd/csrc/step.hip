@@ -237,6 +237,9 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
                 v = (fabsf(S.root_pos_w[ec * 3]) > p0) || (fabsf(S.root_pos_w[ec * 3 + 1]) > p1);
                 break;
             case IMX_T_EXTERNAL: v = S.ext_term[ec * (int64_t)W[IMX_H_NEXT_TERM] + r[IMX_R_AUX0]] != 0; break;
+            case IMX_T_COMMAND_RESAMPLE:  // (time_left <= step_dt) & (command_counter == num_resamples)
+                v = (S.command_time_left[ec] <= p0) && (S.command_counter[ec] == (int64_t)n);
+                break;
             default: break;
         }
         if (r[IMX_R_WEIGHT]) truncated = truncated || v; else terminated = terminated || v;
@@ -252,6 +255,16 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
         const int idx = r[IMX_R_OUT];
         const float es0 = live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f;  // issued early: independent of the term
+        const float weight = f_of(r[IMX_R_WEIGHT]);
+        if (weight == 0.0f) {
+            // skipped by compute (reward_manager.py:145: no value, step_reward keeps what it held), but the slot still takes part in
+            // the reset / log pass (reward_manager.py:100-126)
+            s_val[k * 64 + lane] = 0.0f;
+            const float part = wave_sum(reset ? es0 : 0.0f);
+            if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
+            if (reset) Bf.episode_sums[(size_t)idx * N + e] = 0.0f;
+            continue;
+        }
         const int op = r[IMX_R_OP];
         const int32_t* ids = W + r[IMX_R_IDS_OFF];
         const int n = r[IMX_R_NIDS];
@@ -359,9 +372,15 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
                 f = sum_ids(ids, n, [&](int j) { const float d = wrap_to_pi(S.joint_pos[ec * J + j]) - p0; return d * d; });
                 break;
             case IMX_W_EXTERNAL: f = S.ext_reward[ec * (int64_t)W[IMX_H_NEXT_REW] + r[IMX_R_AUX0]]; break;
+            case IMX_W_BODY_LIN_ACC_L2:  // sum over bodies of ||body_lin_acc_w|| (rewards.py:125-128)
+                f = sum_ids(ids, n, [&](int b) {
+                    const float* a = S.body_lin_acc_w + ((size_t)ec * P.NB + b) * 3;
+                    return norm3(a[0], a[1], a[2]);
+                });
+                break;
             default: break;
         }
-        const float value = f * f_of(r[IMX_R_WEIGHT]) * dt;
+        const float value = f * weight * dt;
         s_val[k * 64 + lane] = value;
         const float es = es0 + value;
         if (live) {
@@ -372,19 +391,11 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         const float part = wave_sum(reset ? es : 0.0f);
         if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
     }
-    // slots of zero-weight terms (skipped by compute, reward_manager.py:145) still take part in the reset/log pass
-    for (int q = wv; q < P.nskip; q += IMX_TR_WAVES) {
-        const int idx = W[P.skip_off + q];
-        const float es = live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f;
-        const float part = wave_sum(reset ? es : 0.0f);
-        if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
-        if (reset) Bf.episode_sums[(size_t)idx * N + e] = 0.0f;
-    }
     __syncthreads();
 
     if (wv == 0) {
         float reward = 0.0f;
-        for (int k = 0; k < P.nrew; ++k) reward += s_val[k * 64 + lane];  // term order
+        for (int k = 0; k < P.nrew; ++k) reward += s_val[k * 64 + lane];  // term order (a skipped term holds +0: x + 0 == x bit for bit)
         // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
         if (live) {
             Bf.reward_buf[e] = reward;
@@ -506,12 +517,14 @@ IMX_DEV XCol load_xcol(const int32_t* __restrict__ W, int off, int i) {
     return x;
 }
 
+// D = width of the whole column space (all groups side by side), gbase = first column of this entry's group in it: the parity-mode
+// uniforms are one (N, D) array, group after group
 IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restrict__ noise_u, uint64_t seed, uint32_t step,
-                       int64_t e, int D) {
+                       int64_t e, int D, int gbase) {
     const int flags = x.a.w;
     if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
         // a term with a history window draws for its first (oldest-slot) columns, like rand_like on the (N, d) term value
-        const int c = x.a.x - (x.d.z - 1) * x.d.w;
+        const int c = gbase + x.a.x - (x.d.z - 1) * x.d.w;
         const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
         const float lo = f_of(x.b.y), hi = f_of(x.b.z);
         const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
@@ -636,11 +649,15 @@ IMX_DEV float obs_plain_value(const PlanView& P, const imx_state_t& S, const imx
 // modifiers -> noise -> clip -> scale -> history window -> obs[e][c] for computed column i (observation_manager.py:305-335)
 IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& x, int i, float v, int64_t e, int corrupt,
                         bool fill_all, const float* __restrict__ noise_u, uint64_t seed, uint32_t step) {
-    const int D = P.D, c = x.a.x;
+    const int c = x.a.x;
+    const int g = (x.a.w >> 8) & 3;  // observation group of this column (ObservationManager.compute loops over the groups)
+    const int gD = g == 0 ? P.gD[0] : (g == 1 ? P.gD[1] : (g == 2 ? P.gD[2] : P.gD[3]));
+    const int gb = g == 0 ? 0 : (g == 1 ? P.gbase[1] : (g == 2 ? P.gbase[2] : P.gbase[3]));
+    float* grow = g == 0 ? Bf.obs : (g == 1 ? Bf.obs_extra1 : (g == 2 ? Bf.obs_extra2 : Bf.obs_extra3));
     if (x.a.w & IMX_F_MODIFIERS)
         v = apply_modifiers(P.w, P.xmod_off + 4 * i, v, Bf.mod_state + e * P.MS, fill_all || Bf.reset_buf[e]);
-    const float vp = obs_post(x, v, corrupt, noise_u, seed, step, e, D);
-    float* o = Bf.obs + e * D + c;  // newest slot
+    const float vp = obs_post(x, v, corrupt & (P.gcorrupt >> g), noise_u, seed, step, e, P.D, gb);
+    float* o = grow + e * gD + c;  // newest slot
     const int hist = x.d.z;
     if (hist > 1) {
         // CircularBuffer.append (utils/buffers/circular_buffer.py:107-135) on the window kept in the obs row itself: this
@@ -669,10 +686,52 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
     const int32_t* __restrict__ W = P.w;
     const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
     const uint32_t step = (uint32_t)Bf.counters[2];
-    const float pz = es[11];
-    const float yw = es[16], yz = es[17], px = es[9], py = es[10];
+    float pz = es[11];
+    const float yw = es[16], yz = es[17];
+    float px = es[9], py = es[10];
     const bool fill_all = (corrupt & 2) != 0;
+    const bool keep_all_hits = (corrupt & 8) != 0;
     corrupt &= 1;
+    // -- the height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide
+    //    whether this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  The
+    //    decision is a function of the env's state only, so every lane of the block takes the same one from the same (scalar) loads;
+    //    the state is double-buffered on the step counter: lanes read slot step&1, thread 0 writes the other -- a second call within
+    //    the same step (ObservationManager.compute() by user code) finds the same inputs and repeats the same outputs.
+    bool cast = true, cache_z = false;
+    if (P.scan_stateful) {
+        const float* st = Bf.scan_state + ((size_t)(step & 1u) * N + e) * 8;
+        float ts = st[0], last = st[1], drx = st[2], dry = st[3], drz = st[4], pz_data = st[5];
+        bool outdated = st[6] != 0.0f;
+        for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
+        outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
+        if (fill_all || Bf.reset_buf[e]) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
+            ts = 0.0f; last = 0.0f; outdated = true;
+            if (Bf.scan_drift_feed) {
+                drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+            } else {
+                const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
+                drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
+                dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
+                drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+            }
+        }
+        cast = outdated;
+        if (cast) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
+            px += drx; py += dry; pz += drz;
+            pz_data = pz;
+            last = ts;
+            float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
+            for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
+            cache_z = keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period);
+        } else {
+            pz = pz_data;  // data.pos_w of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
+        }
+        if (threadIdx.x == 0) {
+            float4* o = reinterpret_cast<float4*>(Bf.scan_state + ((size_t)((step & 1u) ^ 1u) * N + e) * 8);
+            o[0] = make_float4(ts, last, drx, dry);
+            o[1] = make_float4(drz, pz_data, 0.0f, 0.0f);
+        }
+    }
 #ifdef IMX_TRACE
     const uint64_t trace_t0 = wall_clock64();
 #endif
@@ -683,30 +742,42 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
         switch (op) {
             case IMX_O_HEIGHT_SCAN: {
                 // RayCaster._update_buffers_impl (ray_caster.py:242-260) + height_scan (observations.py:165-173)
-                const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
-                float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
-                if (P.ray_yaw_only) {
-                    quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
-                } else {  // ray_caster.py:249-252: full orientation for starts and directions
-                    quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
-                    quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
-                }
-                sx += px; sy += py; sz += pz;
-                float t;
-                int32_t face;
-                float hx, hy, hz;
-                const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
-                                              : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
-                if (hit) {
-                    hx = sx + t * dx; hy = sy + t * dy; hz = sz + t * dz;  // kernels.py:69
+                float hz;
+                if (cast) {
+                    const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
+                    float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
+                    if (P.ray_yaw_only) {
+                        quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
+                    } else {  // ray_caster.py:249-252: full orientation for starts and directions
+                        quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
+                        quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
+                    }
+                    sx += px; sy += py; sz += pz;
+                    float t;
+                    int32_t face;
+                    float hx, hy;
+                    const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
+                                                  : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
+                    if (hit) {
+                        hx = sx + t * dx; hy = sy + t * dy; hz = sz + t * dz;  // kernels.py:69
+                    } else {
+                        hx = hy = hz = __builtin_huge_valf();  // ops.py:70
+                    }
+                    if (ray_hits_out) {
+                        float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
+                        o[0] = hx; o[1] = hy; o[2] = hz;
+                    }
+                    if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
                 } else {
-                    hx = hy = hz = __builtin_huge_valf();  // ops.py:70
-                }
-                if (ray_hits_out) {
-                    float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
-                    o[0] = hx; o[1] = hy; o[2] = hz;
+                    hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
                 }
                 v = pz - hz - f_of(x.b.x);
+                // further height_scan terms on the same sensor (another group, another offset / noise / clip): same hit, own post-processing
+                for (int nx = x.c.z; nx != 0;) {
+                    const XCol tw = load_xcol(W, P.xcol_off, nx - 1);
+                    obs_finish(P, Bf, tw, nx - 1, pz - hz - f_of(tw.b.x), e, corrupt, fill_all, noise_u, seed, step);
+                    nx = tw.c.z;
+                }
             } break;
             default: v = obs_plain_value(P, S, Bf, es, e, x); break;
         }
@@ -805,10 +876,12 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
             case IMX_T_JOINT_VEL_MANUAL_LIMIT: if (need(st->joint_vel, "joint_vel")) return 1; break;
             case IMX_T_JOINT_EFFORT_LIMIT: if (need(st->computed_torque, "computed_torque") || need(st->applied_torque, "applied_torque")) return 1; break;
             case IMX_T_EXTERNAL: if (need(st->ext_term, "ext_term")) return 1; break;
+            case IMX_T_COMMAND_RESAMPLE: if (need(st->command_time_left, "command_time_left") || need(st->command_counter, "command_counter")) return 1; break;
             default: break;
         }
     }
     for (int k = 0; k < plan->nrew; ++k) {
+        if (w[plan->rew_off + k * IMX_REC_WORDS + IMX_R_WEIGHT] == 0) continue;  // +0.0f: skipped at run time, reads nothing
         switch (w[plan->rew_off + k * IMX_REC_WORDS + IMX_R_OP]) {
             case IMX_W_BASE_HEIGHT_L2: if (need(st->root_pos_w, "root_pos_w")) return 1; break;
             case IMX_W_JOINT_TORQUES_L2: if (need(st->applied_torque, "applied_torque")) return 1; break;
@@ -826,6 +899,7 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
             case IMX_W_FEET_SLIDE: if (need(st->net_forces_w_history, "net_forces_w_history") || need(st->body_lin_vel_w, "body_lin_vel_w")) return 1; break;
             case IMX_W_JOINT_POS_TARGET_L2: if (need(st->joint_pos, "joint_pos")) return 1; break;
             case IMX_W_EXTERNAL: if (need(st->ext_reward, "ext_reward")) return 1; break;
+            case IMX_W_BODY_LIN_ACC_L2: if (need(st->body_lin_acc_w, "body_lin_acc_w")) return 1; break;
             default: break;
         }
     }
@@ -854,6 +928,13 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w && st->root_pos_w, "root state missing");
     IMX_REQUIRE(!plan->needs_mesh || mesh, "plan has a height_scan term but no mesh was given");
     IMX_REQUIRE(plan->DC == plan->D || bf->reset_buf, "imx_observations: observation history needs the reset mask (reset_buf)");
+    {
+        const float* extra[3] = {bf->obs_extra1, bf->obs_extra2, bf->obs_extra3};
+        for (int g = 1; g < plan->ngroups; ++g)
+            IMX_REQUIRE(extra[g - 1], "imx_observations: the plan has %d observation groups but obs_extra%d is NULL", plan->ngroups, g);
+    }
+    IMX_REQUIRE(!plan->scan_stateful || (bf->scan_state && bf->scan_hit_z && bf->reset_buf),
+                "imx_observations: the height scanner has an update period / drift range: scan_state (2,N,8), scan_hit_z (N,R) and reset_buf are required");
     IMX_REQUIRE(plan->MS == 0 || (bf->mod_state && bf->reset_buf),
                 "imx_observations: the plan has stateful observation modifiers: mod_state (N x %d floats) and reset_buf are required", plan->MS);
     const auto& w = plan->host;

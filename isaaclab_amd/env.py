@@ -27,6 +27,7 @@ import torch
 from . import _lib
 from ._lib import ImxBuffers, ImxState, check, lib
 from .plan import Plan, compile_plan
+from .plan import func_name as func_name_of
 from .robots import ROBOTS, RobotSpec
 from .state_feed import StateFeed
 
@@ -99,6 +100,28 @@ class TerrainMesh:
 
 
 # ---------------------------------------------------------------------------------------------------- manager views
+class TermCfgView:
+    """What ``get_term_cfg`` hands out (RewardTermCfg / TerminationTermCfg surface: ``func``, ``params``, ``weight`` /
+    ``time_out``): a mutable copy of the term's cfg entry.  Changing it has no effect until it goes back through ``set_term_cfg``,
+    as in the reference where the caller mutates the cfg object and re-installs it (envs/mdp/curriculums.py:32-36)."""
+
+    def __init__(self, entry: dict):
+        import copy
+
+        self.__dict__.update(copy.deepcopy(entry))
+
+    def to_dict(self) -> dict:
+        return dict(self.__dict__)
+
+
+def _cfg_entry(cfg: Any) -> dict:
+    if isinstance(cfg, dict):
+        return dict(cfg)
+    if hasattr(cfg, "to_dict"):
+        return dict(cfg.to_dict())
+    return dict(vars(cfg))
+
+
 class _ActionTermView:
     def __init__(self, env, name, col0, dim):
         self._env, self.name, self._c0, self.action_dim = env, name, col0, dim
@@ -160,35 +183,43 @@ class ActionManager:
 
 
 class ObservationManager:
-    """isaaclab/managers/observation_manager.py:177-335 surface for the fused 'policy' group."""
+    """isaaclab/managers/observation_manager.py:177-335 surface; every (concatenated) group of the cfg is filled by the one fused
+    launch of ``imx_observations``."""
 
-    def __init__(self, env: "ManagerBasedRLEnv", group: str = "policy"):
-        self._env, self._group = env, group
+    def __init__(self, env: "ManagerBasedRLEnv"):
+        self._env = env
+
+    @property
+    def _groups(self):
+        return self._env.plan.obs_groups
 
     @property
     def active_terms(self):
-        return {self._group: [t.name for t in self._env.plan.obs_terms]}
+        return {g.name: [t.name for t in g.terms] for g in self._groups}
 
     @property
     def group_obs_dim(self):
-        return {self._group: (self._env.plan.obs_dim,)}
+        return {g.name: (g.dim,) for g in self._groups}
 
     @property
     def group_obs_term_dim(self):
-        return {self._group: list(self._env.plan.obs_term_dims)}
+        return {g.name: list(g.term_dims) for g in self._groups}
 
     @property
     def group_obs_concatenate(self):
-        return {self._group: True}
+        return {g.name: True for g in self._groups}
 
     def compute(self) -> dict:
-        return {self._group: self.compute_group(self._group)}
+        """observation_manager.py:238-258: every group (one launch fills them all)."""
+        self._env._compute_observations()
+        return dict(self._env.obs_buf)
 
     def compute_group(self, group_name: str):
-        if group_name != self._group:
+        if group_name not in self._env.obs_buf:  # observation_manager.py:293-297
             raise ValueError(f"Unable to find the group '{group_name}' in the observation manager."
-                             f" Available groups are: {[self._group]}")
-        return self._env._compute_observations()
+                             f" Available groups are: {list(self._env.obs_buf)}")
+        self._env._compute_observations()
+        return self._env.obs_buf[group_name]
 
     def reset(self, env_ids=None) -> dict:
         return {}
@@ -213,9 +244,18 @@ class RewardManager:
         return self._reward_buf
 
     def get_term_cfg(self, term_name: str):
+        """reward_manager.py:178-193"""
         if term_name not in self._term_names:
             raise ValueError(f"Reward term '{term_name}' not found.")
-        return self._env.plan.reward_terms[self._term_names.index(term_name)]
+        return TermCfgView(self._env._cfg_dict["rewards"][term_name])
+
+    def set_term_cfg(self, term_name: str, cfg):
+        """reward_manager.py:163-176.  The term tables live on the device: the changed cfg is recompiled and copied over them in
+        place (``imx_plan_update``, stream-ordered; graphs captured on this env stay valid).  A cfg equal to the installed one --
+        ``modify_reward_weight`` re-installs its weight at every reset -- costs a dict comparison."""
+        if term_name not in self._term_names:
+            raise ValueError(f"Reward term '{term_name}' not found.")
+        self._env._install_term_cfg("rewards", term_name, _cfg_entry(cfg))
 
     def reset(self, env_ids=None) -> dict:
         """Episode_Reward/<term> = mean(episode_sum[ids]) / max_episode_length_s, then zero (reward_manager.py:100-126)."""
@@ -264,6 +304,18 @@ class TerminationManager:
         from .robots import resolve_matching_names
 
         return resolve_matching_names(name_keys, self._term_names)[1]
+
+    def get_term_cfg(self, term_name: str):
+        """termination_manager.py:222-237"""
+        if term_name not in self._term_names:
+            raise ValueError(f"Termination term '{term_name}' not found.")
+        return TermCfgView(self._env._cfg_dict["terminations"][term_name])
+
+    def set_term_cfg(self, term_name: str, cfg):
+        """termination_manager.py:207-220 (see RewardManager.set_term_cfg)"""
+        if term_name not in self._term_names:
+            raise ValueError(f"Termination term '{term_name}' not found.")
+        self._env._install_term_cfg("terminations", term_name, _cfg_entry(cfg))
 
     def reset(self, env_ids=None) -> dict:
         ids = slice(None) if env_ids is None else env_ids
@@ -323,6 +375,29 @@ class _Entity:
         return resolve_matching_names(keys, self.body_names, preserve_order)
 
 
+class _SceneEntityView:
+    """``SceneEntityCfg`` as a Python-evaluated term sees it after ``resolve()`` (managers/scene_entity_cfg.py:112-250): ``name``,
+    ``joint_names`` / ``body_names`` and the resolved ``joint_ids`` / ``body_ids`` (``slice(None)`` when every one is selected)."""
+
+    def __init__(self, ent: dict, compiler):
+        self.name = ent.get("name")
+        self.joint_names, self.body_names = ent.get("joint_names"), ent.get("body_names")
+        self.preserve_order = bool(ent.get("preserve_order"))
+        for kind in ("joint", "body"):
+            ids = slice(None)
+            try:
+                n_all = len(compiler._entity_names(self.name, kind))
+                r = compiler.resolve_ids(ent, kind)
+                ids = slice(None) if (ent.get(f"{kind}_names") is None and len(r) == n_all) else r
+            except ValueError:
+                pass  # entity without such a name table (e.g. the height scanner)
+            setattr(self, f"{kind}_ids", ids)
+
+
+def _looks_like_scene_entity(v) -> bool:
+    return isinstance(v, dict) and "name" in v and any(k in v for k in ("joint_names", "body_names", "joint_ids", "body_ids"))
+
+
 class _Scene:
     def __init__(self, env):
         r = env.plan.robot
@@ -379,9 +454,14 @@ class ManagerBasedRLEnv:
                 raise ValueError("pass robot= (RobotSpec or name) or a state_feed when cfg is not a task fixture")
             robot_name = state_feed.robot
         self.render_mode = render_mode
-        self.plan: Plan = compile_plan(env_cfg, robot_name)
+        import copy
+
+        # the env's own copy of the cfg in to_dict() form: set_term_cfg edits and recompiles it
+        self._cfg_dict = copy.deepcopy(env_cfg if isinstance(env_cfg, dict) else env_cfg.to_dict())
+        self._robot = robot_name
+        self.plan: Plan = compile_plan(self._cfg_dict, robot_name)
         plan = self.plan
-        env_dict = env_cfg if isinstance(env_cfg, dict) else env_cfg.to_dict()
+        env_dict = self._cfg_dict
         if device is None:
             device = state_feed.device if state_feed is not None else ("cuda:0" if torch.cuda.is_available() else None)
         if device is None or torch.device(device).type != "cuda":
@@ -433,7 +513,8 @@ class ManagerBasedRLEnv:
         self._reset_env_ids = z(N, dtype=torch.long)
         self._counters = z(8, dtype=torch.int32)
         self._log_out = z(K + NT + 1)
-        self._obs = z(N, max(D, 1))
+        self._obs_groups = [z(N, max(g.dim, 1)) for g in plan.obs_groups]  # one (N, D_g) tensor per observation group
+        self._obs = self._obs_groups[0]
         self._ext_reward = z(N, plan.n_ext_rew) if plan.n_ext_rew else None
         self._ext_term = z(N, plan.n_ext_term, dtype=torch.bool) if plan.n_ext_term else None
         self._ext_obs = z(N, plan.n_ext_obs) if plan.n_ext_obs else None
@@ -441,7 +522,16 @@ class ManagerBasedRLEnv:
         self.materialize_ray_hits = False
         self._ray_hits = None
         self.reward_buf = self._reward_buf
-        self.obs_buf = {"policy": self._obs}
+        self.obs_buf = {g.name: t for g, t in zip(plan.obs_groups, self._obs_groups)}
+        # height scanner as a SensorBase (update_period gating, drift): double-buffered per-env {timestamp, last update, drift xyz,
+        # data.pos_w z, outdated} + the hit heights of envs that skip an update; sensors start outdated (sensor_base.py:_initialize_impl)
+        self._scan_state = self._scan_hit_z = None
+        self._scan_drift_feed: torch.Tensor | None = None  # parity runs: (N,3) drift values taken at a sensor reset
+        self.scanner_keep_all_hits = False  # keep every env's hit heights (set before overwriting the sensor timestamps by hand)
+        if plan.scan_stateful:
+            self._scan_state = z(2, N, 8)
+            self._scan_state[:, :, 6] = 1.0
+            self._scan_hit_z = z(N, plan.num_rays)
 
         blob = np.ascontiguousarray(plan.blob, np.int32)
         self._plan_h = ctypes.c_void_p()
@@ -457,7 +547,9 @@ class ManagerBasedRLEnv:
             terminated=self.reset_terminated.data_ptr(), truncated=self.reset_time_outs.data_ptr(),
             reset_buf=self.reset_buf.data_ptr(), reset_env_ids=self._reset_env_ids.data_ptr(),
             counters=self._counters.data_ptr(), log_out=self._log_out.data_ptr(), obs=self._obs.data_ptr(),
-            scratch=self._scratch.data_ptr(), mod_state=self._mod_state.data_ptr() if self._mod_state is not None else None)
+            scratch=self._scratch.data_ptr(), mod_state=self._mod_state.data_ptr() if self._mod_state is not None else None,
+            scan_state=_lib.ptr(self._scan_state), scan_hit_z=_lib.ptr(self._scan_hit_z),
+            **{f"obs_extra{g}": self._obs_groups[g].data_ptr() for g in range(1, len(self._obs_groups))})
         self._state_cache: dict[int, ImxState] = {}
         self._root_cache = None
 
@@ -505,9 +597,9 @@ class ManagerBasedRLEnv:
                                "joint_pos": torch.zeros(N, J, device=self.device), "joint_vel": torch.zeros(N, J, device=self.device)}
         self.scene = _Scene(self)
         self._ext_funcs = {
-            "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None and t.weight != 0.0],
+            "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None],
             "term": [(t, self._resolve_ext(t)) for t in plan.termination_terms if t.external is not None],
-            "obs": [(t, self._resolve_ext(t)) for t in plan.obs_terms if t.external is not None],
+            "obs": [(t, self._resolve_ext(t)) for g in plan.obs_groups for t in g.terms if t.external is not None],
         }
         names_r = [t.name for t in plan.reward_terms]
         names_t = [t.name for t in plan.termination_terms]
@@ -553,9 +645,43 @@ class ManagerBasedRLEnv:
             pass
 
     # ---- internals -------------------------------------------------------------------------------------------------
+    def _install_term_cfg(self, section: str, term_name: str, entry: dict):
+        old = self._cfg_dict[section][term_name]
+        new = dict(old)
+        new.update({k: v for k, v in entry.items() if k in old or k in ("weight", "params", "func", "time_out")})
+        if new == old:
+            return
+        if func_name_of(new.get("func")) != func_name_of(old.get("func")):
+            raise NotImplementedError(f"set_term_cfg('{term_name}'): replacing a term's function needs a new environment")
+        self._cfg_dict[section][term_name] = new
+        try:
+            plan = compile_plan(self._cfg_dict, self._robot)
+            blob = np.ascontiguousarray(plan.blob, np.int32)
+            check(self._lib.imx_plan_update(self._plan_h, blob.ctypes.data, blob.size, _lib.current_stream(self.device)))
+        except Exception:
+            self._cfg_dict[section][term_name] = old
+            raise
+        # the python-side mirror (term weights / params read by the Python-evaluated route and by get_term_cfg)
+        for cur, fresh in zip(self.plan.reward_terms, plan.reward_terms):
+            cur.weight, cur.params = fresh.weight, fresh.params
+        for cur, fresh in zip(self.plan.termination_terms, plan.termination_terms):
+            cur.params, cur.time_out = fresh.params, fresh.time_out
+        self.plan.blob = plan.blob
+        for kind in ("rew", "term"):
+            for t, _ in self._ext_funcs[kind]:
+                self._resolve_ext(t)  # call-time parameters of Python-evaluated terms follow the new cfg
+
     def _resolve_ext(self, term):
+        """Callable + call-time parameters of a Python-evaluated term (ManagerBase._resolve_common_term_cfg,
+        managers/manager_base.py:278-395: SceneEntityCfg parameters are resolved against the scene once)."""
+        from .plan import PlanCompiler
+
         f = term.external
-        return _string_to_callable(f) if isinstance(f, str) else f
+        fn = _string_to_callable(f) if isinstance(f, str) else f
+        comp = PlanCompiler(self._cfg_dict, self._robot)
+        term.call_params = {k: (_SceneEntityView(v, comp) if _looks_like_scene_entity(v) else v) for k, v in term.params.items()}
+        term.py_mod_funcs = [(_string_to_callable(m) if isinstance(m, str) else m, mp) for m, mp in term.py_modifiers]
+        return fn
 
     def _state(self) -> ImxState:
         idx = self.feed.index
@@ -565,6 +691,8 @@ class ManagerBasedRLEnv:
             kw = {n: snap[n].data_ptr() for n in _lib.STATE_FIELDS if n in snap}
             if self.command_term is not None:
                 kw["command"] = self.command_term.vel_command_b.data_ptr()
+                kw["command_time_left"] = self.command_term.time_left.data_ptr()
+                kw["command_counter"] = self.command_term.command_counter.data_ptr()
             if self.contact_sensor is not None:
                 d = self.contact_sensor.data
                 kw.update(net_forces_w_history=d.net_forces_w_history.data_ptr(), last_air_time=d.last_air_time.data_ptr(),
@@ -597,7 +725,9 @@ class ManagerBasedRLEnv:
 
     def _eval_external(self, kind: str):
         for col, (term, fn) in enumerate(self._ext_funcs[kind]):
-            val = fn(self, **term.params)
+            if kind == "rew" and term.weight == 0.0:
+                continue  # reward_manager.py:145: a zero-weight term is not evaluated
+            val = fn(self, **term.call_params)
             if kind == "rew":
                 self._ext_reward[:, col] = val
             elif kind == "term":
@@ -605,7 +735,10 @@ class ManagerBasedRLEnv:
         if kind == "obs":
             c = 0
             for term, fn in self._ext_funcs["obs"]:
-                self._ext_obs[:, c:c + term.dim] = fn(self, **term.params).reshape(self.num_envs, -1)
+                val = fn(self, **term.call_params)
+                for mfn, mp in term.py_mod_funcs:  # a foreign (function-style) modifier chain: observation_manager.py:310-312
+                    val = mfn(val, **mp)
+                self._ext_obs[:, c:c + term.dim] = val.reshape(self.num_envs, -1)
                 c += term.dim
 
     def _compute_observations(self, fill_history: bool = False, frame_current: bool = False) -> torch.Tensor:
@@ -616,10 +749,12 @@ class ManagerBasedRLEnv:
             if self._ray_hits is None:
                 self._ray_hits = torch.empty(self.num_envs, self.plan.num_rays, 3, device=self.device)
             hits = self._ray_hits.data_ptr()
+        self._bufs.scan_drift_feed = _lib.ptr(self._scan_drift_feed)
         check(self._lib.imx_observations(
             self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
             self.terrain.handle if self.terrain is not None else None, _lib.ptr(self._noise_u), self.noise_seed,
-            (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0) | (4 if frame_current else 0), hits, _lib.current_stream(self.device)))
+            (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0) | (4 if frame_current else 0)
+            | (8 if self.scanner_keep_all_hits else 0), hits, _lib.current_stream(self.device)))
         return self._obs
 
     # ---- MDP operations ------------------------------------------------------------------------------------------
@@ -643,12 +778,12 @@ class ManagerBasedRLEnv:
                                       do_compute=False)
         # ObservationManager.reset -> CircularBuffer.reset: the history windows of the reset envs restart from this observation
         if env_ids is None:
-            obs = self._compute_observations(fill_history=True)
+            self._compute_observations(fill_history=True)
         else:
             self.reset_buf.zero_()
             self.reset_buf[ids] = True
-            obs = self._compute_observations()
-        return {"policy": obs}, self.extras
+            self._compute_observations()
+        return dict(self.obs_buf), self.extras
 
     def step(self, action: torch.Tensor):
         """ManagerBasedRLEnv.step (manager_based_rl_env.py:153-242)."""
@@ -679,8 +814,8 @@ class ManagerBasedRLEnv:
             self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], self.reset_buf)
         # -- observations on the post-reset state (one kernel, ray-cast fused); imx_terminations_rewards left the frame table of
         #    this state snapshot behind (the feed's root state is not rewritten by the reset events: they go to sim_writes)
-        obs = self._compute_observations(frame_current=True)
-        return {"policy": obs}, self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+        self._compute_observations(frame_current=True)
+        return dict(self.obs_buf), self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     @property
     def cfg_decimation(self) -> int:

@@ -23,27 +23,31 @@ from .robots import RobotSpec, resolve_matching_names, resolve_matching_names_va
 
 # ---- constants mirrored from include/imx.h (tests/test_boundary.py checks they agree) --------------------------
 MAGIC = 0x31584D49
-PLAN_VERSION = 2
-HEADER_WORDS = 40
+PLAN_VERSION = 3
+HEADER_WORDS = 48
+MAX_OBS_GROUPS = 4
 REC_WORDS = 20
 H = dict(MAGIC=0, VERSION=1, J=2, B=3, H=4, A=5, D=6, R=7, NTERM=8, NREW=9, NOBS=10, NACT=11, MAX_EP_LEN=12,
          STEP_DT=13, TERM_OFF=14, REW_OFF=15, OBS_OFF=16, ACT_OFF=17, TOTAL_WORDS=18, NB=19, GRAV_X=20, GRAV_Y=21,
          GRAV_Z=22, NREW_ALL=23, RAY_OFF=24, RAYDIR_X=25, RAYDIR_Y=26, RAYDIR_Z=27, RAY_MAXDIST=28, MAX_EP_LEN_S=29,
-         NEXT_REW=30, NEXT_TERM=31, NEXT_OBS=32, RAY_YAW_ONLY=33, CMD_DIM=34, MOD_STATE=35)
+         NEXT_REW=30, NEXT_TERM=31, NEXT_OBS=32, RAY_YAW_ONLY=33, CMD_DIM=34, MOD_STATE=35, NGROUPS=36, GROUP_OFF=37,
+         SCAN_PERIOD=38, SCAN_DT=39, SCAN_SUBSTEPS=40, SCAN_DRIFT_LO=41, SCAN_DRIFT_HI=42, SCAN_STATEFUL=43)
 R = dict(OP=0, IDS_OFF=1, NIDS=2, IDS2_OFF=3, NIDS2=4, WEIGHT=5, P0=6, P1=7, P2=8, P3=9, OUT=10, DIM=11, FLAGS=12,
          NOISE_LO=13, NOISE_HI=14, CLIP_LO=15, CLIP_HI=16, SCALE=17, AUX0=18, AUX1=19)
-F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE, F_MODIFIERS = 1, 2, 4, 8, 16, 32, 64
+F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE, F_MODIFIERS, F_SCAN_TWIN = 1, 2, 4, 8, 16, 32, 64, 128
 M_OPS = dict(SCALE=1, BIAS=2, CLIP=3, INTEGRATOR=4, DIGITAL_FILTER=5)
 F_ACT_DEFAULT_POS_OFFSET, F_ACT_DEFAULT_VEL_OFFSET, F_ACT_CLIP = 1, 2, 4
 
 T_OPS = dict(TIME_OUT=1, ILLEGAL_CONTACT=2, JOINT_POS_MANUAL_LIMIT=3, BAD_ORIENTATION=4, ROOT_HEIGHT_BELOW_MIN=5,
-             JOINT_VEL_LIMIT=6, JOINT_VEL_MANUAL_LIMIT=7, JOINT_EFFORT_LIMIT=8, TERRAIN_OUT_OF_BOUNDS=9, EXTERNAL=10)
+             JOINT_VEL_LIMIT=6, JOINT_VEL_MANUAL_LIMIT=7, JOINT_EFFORT_LIMIT=8, TERRAIN_OUT_OF_BOUNDS=9, EXTERNAL=10,
+             COMMAND_RESAMPLE=11)
 W_OPS = dict(IS_ALIVE=1, IS_TERMINATED=2, IS_TERMINATED_TERM=3, LIN_VEL_Z_L2=4, ANG_VEL_XY_L2=5, FLAT_ORIENTATION_L2=6,
              BASE_HEIGHT_L2=7, JOINT_TORQUES_L2=8, JOINT_VEL_L1=9, JOINT_VEL_L2=10, JOINT_ACC_L2=11,
              JOINT_DEVIATION_L1=12, JOINT_POS_LIMITS=13, JOINT_VEL_LIMITS=14, APPLIED_TORQUE_LIMITS=15,
              ACTION_RATE_L2=16, ACTION_L2=17, UNDESIRED_CONTACTS=18, CONTACT_FORCES=19, TRACK_LIN_VEL_XY_EXP=20,
              TRACK_ANG_VEL_Z_EXP=21, FEET_AIR_TIME=22, FEET_AIR_TIME_POSITIVE_BIPED=23, FEET_SLIDE=24,
-             TRACK_LIN_VEL_XY_YAW_FRAME_EXP=25, TRACK_ANG_VEL_Z_WORLD_EXP=26, JOINT_POS_TARGET_L2=27, EXTERNAL=28)
+             TRACK_LIN_VEL_XY_YAW_FRAME_EXP=25, TRACK_ANG_VEL_Z_WORLD_EXP=26, JOINT_POS_TARGET_L2=27, EXTERNAL=28,
+             BODY_LIN_ACC_L2=29)
 O_OPS = dict(BASE_POS_Z=1, BASE_LIN_VEL=2, BASE_ANG_VEL=3, PROJECTED_GRAVITY=4, ROOT_POS_W=5, ROOT_QUAT_W=6,
              ROOT_LIN_VEL_W=7, ROOT_ANG_VEL_W=8, JOINT_POS=9, JOINT_POS_REL=10, JOINT_POS_LIMIT_NORMALIZED=11,
              JOINT_VEL=12, JOINT_VEL_REL=13, HEIGHT_SCAN=14, LAST_ACTION=15, GENERATED_COMMANDS=16, EXTERNAL=17)
@@ -99,6 +103,7 @@ class Term:
     dim: int = 1
     weight: float = 0.0
     time_out: bool = False
+    py_modifiers: list = dataclasses.field(default_factory=list)  # (func, params) of a foreign modifier chain applied in Python
 
 
 @dataclasses.dataclass
@@ -131,6 +136,21 @@ class Plan:
     n_ext_obs: int = 0
     mod_state_dim: int = 0  # floats of observation-modifier state per env (DigitalFilter / Integrator)
     gravity_dir: tuple[float, float, float] = (0.0, 0.0, -1.0)
+    obs_groups: list = dataclasses.field(default_factory=list)  # every observation group (ObsGroup), cfg order; [0] = obs_terms/obs_dim
+    obs_dim_total: int = 0  # sum of the group widths (= width of the parity-mode noise feed)
+    scan_stateful: bool = False  # the height scanner keeps per-env timestamps / drift (update_period > 0 or a drift range)
+    scan_drift_range: tuple[float, float] = (0.0, 0.0)
+
+
+@dataclasses.dataclass
+class ObsGroup:
+    name: str
+    enable_corruption: bool = False
+    first_record: int = 0
+    num_records: int = 0
+    dim: int = 0
+    terms: list = dataclasses.field(default_factory=list)
+    term_dims: list = dataclasses.field(default_factory=list)
 
 
 class _Blob:
@@ -374,6 +394,9 @@ class PlanCompiler:
             elif fn == f"{_MDP}.terminations:joint_effort_out_of_limit":
                 ids = self.resolve_ids(p.get("asset_cfg"), "joint")
                 rec.update(op=T_OPS["JOINT_EFFORT_LIMIT"], ids_off=blob.ints(ids), nids=len(ids))
+            elif fn == f"{_MDP}.terminations:command_resample":
+                # time_left (f32) <= step_dt and command_counter == num_resamples (terminations.py:35-42)
+                rec.update(op=T_OPS["COMMAND_RESAMPLE"], p0=f32(step_dt), nids=int(p.get("num_resamples", 1)))
             elif fn == f"{_VEL}.terminations:terrain_out_of_bounds":
                 terr = scene.get("terrain") or {}
                 if terr.get("terrain_type") == "plane" or not terr.get("terrain_generator"):
@@ -392,7 +415,7 @@ class PlanCompiler:
             term_terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"],
                                    time_out=bool(tcfg.get("time_out"))))
 
-        # ---- rewards (zero-weight terms keep their slot but are skipped: reward_manager.py:145)
+        # ---- rewards (zero-weight terms keep their slot and record but are skipped at run time: reward_manager.py:145)
         rew_terms: list[Term] = []
         rew_recs: list[list[int]] = []
         n_ext_rew = 0
@@ -462,148 +485,184 @@ class PlanCompiler:
             elif fn == f"{_CART}.rewards:joint_pos_target_l2":
                 joints()
                 rec.update(op=W_OPS["JOINT_POS_TARGET_L2"], p0=f32(p["target"]))
+            elif fn == f"{_MDP}.rewards:body_lin_acc_l2":
+                ids = self.resolve_ids(p.get("asset_cfg"), "body")
+                rec.update(op=W_OPS["BODY_LIN_ACC_L2"], ids_off=blob.ints(ids), nids=len(ids))
             else:
                 known = False
                 rec.update(op=W_OPS["EXTERNAL"], aux0=n_ext_rew)
                 n_ext_rew += 1
             term = Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], weight=float(weight))
             rew_terms.append(term)
-            if float(weight) != 0.0:
-                rew_recs.append(_rec(**rec))
-            elif not known:
-                n_ext_rew -= 1  # never evaluated
+            rew_recs.append(_rec(**rec))  # zero-weight terms keep their record: the kernel skips them at run time, set_term_cfg can wake them
 
-        # ---- observations: only the "policy"-style concatenated groups are fused; first group = main obs
-        obs_groups = cfg.get("observations") or {}
-        group_names = [g_ for g_, v in obs_groups.items() if isinstance(v, dict)]
+        # ---- observations (ObservationManager._prepare_terms, observation_manager.py:337-470): every group of the cfg, in cfg order;
+        #      group g fills its own (N, D_g) tensor.  Record OUT = column inside the group, WEIGHT word = group index.
+        obs_groups_cfg = cfg.get("observations") or {}
+        group_names = [g_ for g_, v in obs_groups_cfg.items() if isinstance(v, dict)]
         if not group_names:
             raise ValueError("env cfg has no observation groups")
-        gname = "policy" if "policy" in group_names else group_names[0]
-        gcfg = obs_groups[gname]
-        if not gcfg.get("concatenate_terms", True):
-            raise NotImplementedError("non-concatenated observation groups are not on the fused path")
-        corruption = bool(gcfg.get("enable_corruption", False))
-        obs_terms: list[Term] = []
+        if len(group_names) > MAX_OBS_GROUPS:
+            raise NotImplementedError(f"{len(group_names)} observation groups; the fused path carries at most {MAX_OBS_GROUPS}")
         obs_recs: list[list[int]] = []
-        obs_dims: list[tuple[int, ...]] = []
+        groups: list[ObsGroup] = []
         n_ext_obs = 0
-        D = 0
         mod_state = 0  # floats of modifier state per env
         ray_local = None
         scanner = scene.get("height_scanner")
         ray_dir = (0.0, 0.0, -1.0)
         ray_max = 1.0e6
         R_n = 0
+        scan_primary = -1  # obs record index of the first height_scan term: later ones reuse its ray hits (one cast per ray and step)
         group_keys = ("concatenate_terms", "enable_corruption", "history_length", "flatten_history_dim")
-        for name, tcfg in gcfg.items():
-            if name in group_keys or tcfg is None or not isinstance(tcfg, dict) or "func" not in tcfg:
-                continue
-            fn = func_name(tcfg["func"])
-            p = dict(tcfg.get("params") or {})
-            # history (observation_manager.py:412-431): a group-level history_length overrides the terms'; the (N,H,d) window
-            # is flattened oldest-first into H*d columns (flatten_history_dim); kept in the obs buffer itself by the kernel
-            gh = gcfg.get("history_length")
-            hist = int(gh if gh is not None else (tcfg.get("history_length") or 0))
-            flat = gcfg.get("flatten_history_dim", True) if gh is not None else tcfg.get("flatten_history_dim", True)
-            if hist > 0 and not flat:
-                raise NotImplementedError(f"observation term '{name}': un-flattened history is not on the fused path")
-            rec = dict(out=D)
-            flags = 0
-            known = True
-            mod_prog, mod_slots = [], 0
-            if tcfg.get("modifiers"):
-                try:
-                    mod_prog, mod_slots = compile_modifiers(tcfg["modifiers"])
-                    last = _short(func_name(tcfg["modifiers"][-1]["func"]))[1]
-                    # the reference's Integrator returns its state tensor itself; a following in-place clip_/mul_ (no noise in
-                    # between) would write into that state -- not reproduced, such a term stays in Python
-                    if last == "Integrator" and not (tcfg.get("noise") and corruption) and (tcfg.get("clip") is not None or tcfg.get("scale") is not None):
+        for gi, gname in enumerate(group_names):
+            gcfg = obs_groups_cfg[gname]
+            if not gcfg.get("concatenate_terms", True):
+                raise NotImplementedError(f"observation group '{gname}': non-concatenated groups are not on the fused path")
+            grp = ObsGroup(name=gname, enable_corruption=bool(gcfg.get("enable_corruption", False)), first_record=len(obs_recs))
+            D = 0
+            for name, tcfg in gcfg.items():
+                if name in group_keys or tcfg is None or not isinstance(tcfg, dict) or "func" not in tcfg:
+                    continue
+                fn = func_name(tcfg["func"])
+                p = dict(tcfg.get("params") or {})
+                # history (observation_manager.py:412-431): a group-level history_length overrides the terms'; the (N,H,d) window
+                # is flattened oldest-first into H*d columns (flatten_history_dim); kept in the obs buffer itself by the kernel
+                gh = gcfg.get("history_length")
+                hist = int(gh if gh is not None else (tcfg.get("history_length") or 0))
+                flat = gcfg.get("flatten_history_dim", True) if gh is not None else tcfg.get("flatten_history_dim", True)
+                if hist > 0 and not flat:
+                    raise NotImplementedError(f"observation term '{name}': un-flattened history is not on the fused path")
+                rec = dict(out=D, weight=int(gi))
+                flags = 0
+                known = True  # the term FUNCTION is one of the fused ops (else: evaluated by calling the Python term, IMX_O_EXTERNAL)
+                # modifiers (observation_manager.py:310-312): modifier.py's five compile to a per-term program run by the kernel on the raw
+                # value, whatever produced it.  A chain with a modifier from elsewhere is applied in Python, right after the (then
+                # Python-evaluated) term function -- possible for function-style modifiers only (stateful classes need the manager)
+                mod_prog, mod_slots, py_mods = [], 0, []
+                if tcfg.get("modifiers"):
+                    try:
+                        mod_prog, mod_slots = compile_modifiers(tcfg["modifiers"])
+                    except NotImplementedError:
+                        for m in tcfg["modifiers"]:
+                            m = m if isinstance(m, dict) else m.to_dict()
+                            if _short(func_name(m["func"]))[1][:1].isupper():
+                                raise NotImplementedError(
+                                    f"observation term '{name}': class-based modifier {func_name(m['func'])} next to a modifier that is not one of "
+                                    "isaaclab.utils.modifiers' five cannot run on the fused path")
+                            py_mods.append((m["func"], dict(m.get("params") or {})))
                         known = False
-                except NotImplementedError:
-                    known = False
-            fixed = {f"{_MDP}.observations:base_pos_z": ("BASE_POS_Z", 1), f"{_MDP}.observations:base_lin_vel": ("BASE_LIN_VEL", 3),
-                     f"{_MDP}.observations:base_ang_vel": ("BASE_ANG_VEL", 3),
-                     f"{_MDP}.observations:projected_gravity": ("PROJECTED_GRAVITY", 3),
-                     f"{_MDP}.observations:root_pos_w": ("ROOT_POS_W", 3), f"{_MDP}.observations:root_quat_w": ("ROOT_QUAT_W", 4),
-                     f"{_MDP}.observations:root_lin_vel_w": ("ROOT_LIN_VEL_W", 3),
-                     f"{_MDP}.observations:root_ang_vel_w": ("ROOT_ANG_VEL_W", 3)}
-            jointy = {f"{_MDP}.observations:joint_pos": "JOINT_POS", f"{_MDP}.observations:joint_pos_rel": "JOINT_POS_REL",
-                      f"{_MDP}.observations:joint_pos_limit_normalized": "JOINT_POS_LIMIT_NORMALIZED",
-                      f"{_MDP}.observations:joint_vel": "JOINT_VEL", f"{_MDP}.observations:joint_vel_rel": "JOINT_VEL_REL"}
-            dim = 0
-            if not known:
-                pass
-            elif fn in fixed:
-                opn, dim = fixed[fn]
-                rec["op"] = O_OPS[opn]
-                if opn == "ROOT_QUAT_W" and p.get("make_quat_unique"):
-                    flags |= F_QUAT_UNIQUE
-            elif fn in jointy:
-                ids = self.resolve_ids(p.get("asset_cfg"), "joint")
-                dim = len(ids)
-                rec.update(op=O_OPS[jointy[fn]], ids_off=blob.ints(ids), nids=dim)
-            elif fn == f"{_MDP}.observations:last_action" and p.get("action_name") is None:
-                rec["op"], dim = O_OPS["LAST_ACTION"], A
-            elif fn == f"{_MDP}.observations:generated_commands":
-                rec["op"], dim = O_OPS["GENERATED_COMMANDS"], 3
-            elif fn == f"{_MDP}.observations:height_scan":
-                if scanner is None:
-                    raise ValueError(f"Error while parsing '{name}:sensor_cfg'. The scene entity 'height_scanner' does not exist.")
-                pc = scanner["pattern_cfg"]
-                if _short(func_name(pc["func"]))[1] != "grid_pattern":
-                    raise NotImplementedError("only grid_pattern ray patterns are on the fused path")
-                starts, dirs = grid_pattern(pc["resolution"], pc["size"], tuple(pc.get("direction", (0.0, 0.0, -1.0))),
-                                            pc.get("ordering", "xy"))
-                off = scanner.get("offset") or {}
-                starts = starts + np.asarray(off.get("pos", (0.0, 0.0, 0.0)), np.float32)
-                d0 = _quat_apply_np(off.get("rot", (1.0, 0.0, 0.0, 0.0)), dirs[0])
-                ray_local, ray_dir, R_n = starts, tuple(float(x) for x in d0), len(starts)
-                ray_max = float(scanner.get("max_distance", 1.0e6))
-                rec.update(op=O_OPS["HEIGHT_SCAN"], p0=f32(p.get("offset", 0.5)))
-                dim = R_n
-            else:
-                known = False
-            noise = tcfg.get("noise")
-            if known and noise:
-                nfn = _short(func_name(noise["func"]))[1]
-                if nfn != "uniform_noise" or not isinstance(noise.get("n_min"), (int, float)):
-                    known = False
+                    last = _short(func_name(tcfg["modifiers"][-1]["func"] if isinstance(tcfg["modifiers"][-1], dict) else tcfg["modifiers"][-1].func))[1]
+                    # the reference's Integrator returns its state tensor itself; a following in-place clip_/mul_ (no noise in
+                    # between) writes into that state -- a reference quirk the fused path does not reproduce: refuse instead of differing
+                    if last == "Integrator" and not (tcfg.get("noise") and grp.enable_corruption) and (tcfg.get("clip") is not None or tcfg.get("scale") is not None):
+                        raise NotImplementedError(
+                            f"observation term '{name}': an Integrator as last modifier followed by clip/scale without noise aliases the "
+                            "integrator state in the reference (modifier.py:247-259, observation_manager.py:314-317); not supported")
+                fixed = {f"{_MDP}.observations:base_pos_z": ("BASE_POS_Z", 1), f"{_MDP}.observations:base_lin_vel": ("BASE_LIN_VEL", 3),
+                         f"{_MDP}.observations:base_ang_vel": ("BASE_ANG_VEL", 3),
+                         f"{_MDP}.observations:projected_gravity": ("PROJECTED_GRAVITY", 3),
+                         f"{_MDP}.observations:root_pos_w": ("ROOT_POS_W", 3), f"{_MDP}.observations:root_quat_w": ("ROOT_QUAT_W", 4),
+                         f"{_MDP}.observations:root_lin_vel_w": ("ROOT_LIN_VEL_W", 3),
+                         f"{_MDP}.observations:root_ang_vel_w": ("ROOT_ANG_VEL_W", 3)}
+                jointy = {f"{_MDP}.observations:joint_pos": "JOINT_POS", f"{_MDP}.observations:joint_pos_rel": "JOINT_POS_REL",
+                          f"{_MDP}.observations:joint_pos_limit_normalized": "JOINT_POS_LIMIT_NORMALIZED",
+                          f"{_MDP}.observations:joint_vel": "JOINT_VEL", f"{_MDP}.observations:joint_vel_rel": "JOINT_VEL_REL"}
+                dim = 0
+                if not known:
+                    pass
+                elif fn in fixed:
+                    opn, dim = fixed[fn]
+                    rec["op"] = O_OPS[opn]
+                    if opn == "ROOT_QUAT_W" and p.get("make_quat_unique"):
+                        flags |= F_QUAT_UNIQUE
+                elif fn in jointy:
+                    ids = self.resolve_ids(p.get("asset_cfg"), "joint")
+                    dim = len(ids)
+                    rec.update(op=O_OPS[jointy[fn]], ids_off=blob.ints(ids), nids=dim)
+                elif fn == f"{_MDP}.observations:last_action" and p.get("action_name") is None:
+                    rec["op"], dim = O_OPS["LAST_ACTION"], A
+                elif fn == f"{_MDP}.observations:generated_commands":
+                    rec["op"], dim = O_OPS["GENERATED_COMMANDS"], 3
+                elif fn == f"{_MDP}.observations:height_scan":
+                    if scanner is None:
+                        raise ValueError(f"Error while parsing '{name}:sensor_cfg'. The scene entity 'height_scanner' does not exist.")
+                    if ray_local is None:
+                        pc = scanner["pattern_cfg"]
+                        if _short(func_name(pc["func"]))[1] != "grid_pattern":
+                            raise NotImplementedError("only grid_pattern ray patterns are on the fused path")
+                        starts, dirs = grid_pattern(pc["resolution"], pc["size"], tuple(pc.get("direction", (0.0, 0.0, -1.0))),
+                                                    pc.get("ordering", "xy"))
+                        off = scanner.get("offset") or {}
+                        starts = starts + np.asarray(off.get("pos", (0.0, 0.0, 0.0)), np.float32)
+                        d0 = _quat_apply_np(off.get("rot", (1.0, 0.0, 0.0, 0.0)), dirs[0])
+                        ray_local, ray_dir, R_n = starts, tuple(float(x) for x in d0), len(starts)
+                        ray_max = float(scanner.get("max_distance", 1.0e6))
+                    rec.update(op=O_OPS["HEIGHT_SCAN"], p0=f32(p.get("offset", 0.5)))
+                    dim = R_n
+                    if scan_primary >= 0 and hist == 0:
+                        flags |= F_SCAN_TWIN  # shares the rays of record `scan_primary` (AUX0)
+                        rec["aux0"] = scan_primary
                 else:
-                    flags |= {"add": F_NOISE_ADD, "scale": F_NOISE_SCALE, "abs": F_NOISE_ABS}[noise.get("operation", "add")]
-                    rec.update(noise_lo=f32(noise["n_min"]), noise_hi=f32(noise["n_max"]))
-            if known and tcfg.get("clip") is not None:
-                flags |= F_CLIP
-                rec.update(clip_lo=f32(tcfg["clip"][0]), clip_hi=f32(tcfg["clip"][1]))
-            if known and tcfg.get("scale") is not None:
-                if isinstance(tcfg["scale"], (int, float)):
+                    known = False
+                if not known:
+                    # the term function (and a foreign modifier chain) is evaluated in Python; the kernel still applies modifier.py's
+                    # modifiers, uniform noise, clip and scale to the value.  Its width comes with the cfg.
+                    rec = dict(out=D, weight=int(gi), op=O_OPS["EXTERNAL"], aux0=n_ext_obs)
+                    flags = 0
+                    dim = int(tcfg.get("_dim", 0))
+                    if dim <= 0:
+                        raise NotImplementedError(
+                            f"observation term '{name}' ({fn}) is not on the fused path; give its width as cfg['_dim']")
+                    n_ext_obs += dim
+                    if hist > 0:
+                        raise NotImplementedError(f"observation term '{name}': history on a term evaluated in Python is not supported")
+                noise = tcfg.get("noise")
+                if noise:  # only the reference's uniform_noise on scalars runs in the kernel; anything else must not be dropped silently
+                    nfn = _short(func_name(noise["func"]))[1]
+                    if nfn != "uniform_noise" or not isinstance(noise.get("n_min"), (int, float)) or not isinstance(noise.get("n_max"), (int, float)):
+                        if grp.enable_corruption:
+                            raise NotImplementedError(f"observation term '{name}': noise model {func_name(noise['func'])} is not on the fused path "
+                                                      "(uniform_noise with scalar bounds is)")
+                    else:
+                        flags |= {"add": F_NOISE_ADD, "scale": F_NOISE_SCALE, "abs": F_NOISE_ABS}[noise.get("operation", "add")]
+                        rec.update(noise_lo=f32(noise["n_min"]), noise_hi=f32(noise["n_max"]))
+                if tcfg.get("clip") is not None:
+                    flags |= F_CLIP
+                    rec.update(clip_lo=f32(tcfg["clip"][0]), clip_hi=f32(tcfg["clip"][1]))
+                if tcfg.get("scale") is not None:
+                    if not isinstance(tcfg["scale"], (int, float)):
+                        raise NotImplementedError(f"observation term '{name}': only a scalar `scale` is on the fused path")
                     flags |= F_SCALE
                     rec["scale"] = f32(tcfg["scale"])
-                else:
-                    known = False
-            if not known:
-                # whole term (incl. its modifiers/noise/clip/scale) evaluated in Python; dim found at first call
-                rec = dict(out=D, op=O_OPS["EXTERNAL"], aux0=n_ext_obs)
-                flags = 0
-                dim = int(tcfg.get("_dim", 0))
-                if dim <= 0:
-                    raise NotImplementedError(
-                        f"observation term '{name}' ({fn}) is not on the fused path; give its width as cfg['_dim']")
-                n_ext_obs += dim
-                if hist > 0:
-                    raise NotImplementedError(f"observation term '{name}': history on a term evaluated in Python is not supported")
-            if known and mod_prog:
-                flags |= F_MODIFIERS
-                rec.update(ids2_off=blob.ints(mod_prog), nids2=len(mod_prog), p1=int(mod_state))
-                mod_state += mod_slots * dim
-            width = max(hist, 1) * dim
-            rec.update(dim=dim, flags=flags, aux1=hist)
-            obs_recs.append(_rec(**rec))
-            obs_terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], dim=width))
-            obs_dims.append((width,))
-            D += width
+                if rec["op"] == O_OPS["HEIGHT_SCAN"] and scan_primary < 0:
+                    scan_primary = len(obs_recs)
+                if mod_prog:
+                    flags |= F_MODIFIERS
+                    rec.update(ids2_off=blob.ints(mod_prog), nids2=len(mod_prog), p1=int(mod_state))
+                    mod_state += mod_slots * dim
+                width = max(hist, 1) * dim
+                rec.update(dim=dim, flags=flags, aux1=hist)
+                obs_recs.append(_rec(**rec))
+                grp.terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], dim=width, py_modifiers=py_mods))
+                grp.term_dims.append((width,))
+                D += width
+            grp.dim = D
+            grp.num_records = len(obs_recs) - grp.first_record
+            groups.append(grp)
+        D = sum(g_.dim for g_ in groups)
+        obs_terms = groups[0].terms
+        obs_dims = groups[0].term_dims
+        corruption = any(g_.enable_corruption for g_ in groups)
+
+        # ---- height scanner as a SensorBase: update_period gating and drift (sensor_base.py:196-205,287-297; ray_caster.py:107-114)
+        scan_period = float((scanner or {}).get("update_period", 0.0) or 0.0)
+        drift = tuple((scanner or {}).get("drift_range", (0.0, 0.0)) or (0.0, 0.0))
+        scan_stateful = bool(R_n > 0 and (scan_period > 0.0 or drift[0] != 0.0 or drift[1] != 0.0))
 
         # ---- assemble
         ray_off = blob.floats(ray_local.reshape(-1)) if ray_local is not None else 0
+        group_off = blob.ints([x for g_ in groups for x in (g_.dim, int(g_.enable_corruption), g_.first_record, g_.num_records)])
         term_off = blob.table(term_recs)
         rew_off = blob.table(rew_recs)
         obs_off = blob.table(obs_recs)
@@ -616,17 +675,20 @@ class PlanCompiler:
             "TOTAL_WORDS": len(w), "NB": B, "NREW_ALL": len(rew_terms), "RAY_OFF": ray_off,
             "NEXT_REW": n_ext_rew, "NEXT_TERM": n_ext_term, "NEXT_OBS": n_ext_obs,
             "RAY_YAW_ONLY": 1 if (scanner and scanner.get("attach_yaw_only")) else 0, "CMD_DIM": 3,
-            "MOD_STATE": mod_state,
+            "MOD_STATE": mod_state, "NGROUPS": len(groups), "GROUP_OFF": group_off, "SCAN_SUBSTEPS": int(cfg["decimation"]),
+            "SCAN_STATEFUL": int(scan_stateful),
         }
         for k, v in hdr.items():
             w[H[k]] = int(v)
         for k, v in {"STEP_DT": f32(step_dt), "GRAV_X": gdir[0], "GRAV_Y": gdir[1], "GRAV_Z": gdir[2],
                      "RAYDIR_X": ray_dir[0], "RAYDIR_Y": ray_dir[1], "RAYDIR_Z": ray_dir[2], "RAY_MAXDIST": ray_max,
-                     "MAX_EP_LEN_S": f32(max_len_s)}.items():
+                     "MAX_EP_LEN_S": f32(max_len_s), "SCAN_PERIOD": f32(scan_period), "SCAN_DT": f32(cfg["sim"]["dt"]),
+                     "SCAN_DRIFT_LO": f32(drift[0]), "SCAN_DRIFT_HI": f32(drift[1])}.items():
             w[H[k]] = _f2w(float(v))
         arr = np.asarray(w, dtype=np.int64)
         arr = np.where(arr >= 2 ** 31, arr - 2 ** 32, arr).astype(np.int32)
-        return Plan(blob=arr, robot=robot, num_joints=J, num_bodies=B, history=Hh, action_dim=A, obs_dim=D, num_rays=R_n,
+        return Plan(blob=arr, robot=robot, num_joints=J, num_bodies=B, history=Hh, action_dim=A, obs_dim=groups[0].dim, num_rays=R_n,
+                    obs_groups=groups, obs_dim_total=D, scan_stateful=scan_stateful, scan_drift_range=(float(drift[0]), float(drift[1])),
                     cmd_dim=3, step_dt=step_dt, max_episode_length=max_len, max_episode_length_s=max_len_s,
                     is_finite_horizon=bool(cfg.get("is_finite_horizon", False)), reward_terms=rew_terms,
                     termination_terms=term_terms, obs_terms=obs_terms, obs_term_dims=obs_dims,

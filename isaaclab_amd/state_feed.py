@@ -22,6 +22,9 @@ DYNAMIC = (
     "body_lin_vel_w", "command", "net_forces_w_history",
     "last_air_time", "current_air_time", "current_contact_time", "last_contact_time",
 )
+# further per-step tensors only a few optional terms read (body_lin_acc_l2, command_resample): drawn from their own generator so that
+# the tensors above are unchanged by their presence; recorded fixtures carry them only when their cfg needs them
+EXTRA = ("body_lin_acc_w", "command_time_left", "command_counter")
 # tensors fixed for the lifetime of the scene
 STATIC = ("default_joint_pos", "default_joint_vel", "soft_joint_pos_limits", "soft_joint_vel_limits", "env_origins")
 
@@ -130,6 +133,16 @@ def generate_snapshot(robot: RobotSpec, num_envs: int, gen: torch.Generator, his
     return out
 
 
+def generate_extras(robot: RobotSpec, num_envs: int, gen: torch.Generator) -> dict[str, torch.Tensor]:
+    """``ArticulationData.body_lin_acc_w`` and the command term's ``time_left`` / ``command_counter`` (CommandTerm,
+    isaaclab/managers/command_manager.py:55-62): N(0, 5) accelerations; time_left ~ U(0, 0.1) s and counters in {0,1,2} so that
+    ``command_resample`` fires on a few envs."""
+    N, B = num_envs, robot.num_bodies
+    return {"body_lin_acc_w": torch.randn(N, B, 3, generator=gen) * 5.0,
+            "command_time_left": torch.rand(N, generator=gen) * 0.1,
+            "command_counter": torch.randint(0, 3, (N,), generator=gen, dtype=torch.int64)}
+
+
 class StateFeed:
     """``S`` snapshots of the post-physics state held on ``device``; ``advance()`` moves to the next one.
 
@@ -148,7 +161,10 @@ class StateFeed:
         gen = torch.Generator().manual_seed(seed)
         snaps = [generate_snapshot(robot, num_envs, gen, history, extent_xy=extent_xy) for _ in range(num_snapshots)]
         self._stack: dict[str, torch.Tensor] = {}
-        for name in DYNAMIC:
+        gen_x = torch.Generator().manual_seed(seed + 0x5EED)
+        for sn in snaps:
+            sn.update(generate_extras(robot, num_envs, gen_x))
+        for name in DYNAMIC + EXTRA:
             self._stack[name] = torch.stack([s[name] for s in snaps], dim=0).to(self.device).contiguous()
         # every snapshot keeps the same origins/defaults; root xy of later snapshots re-uses snapshot-0 origins
         self._static = {name: snaps[0][name].to(self.device).contiguous() for name in STATIC}
@@ -170,7 +186,8 @@ class StateFeed:
         self.num_envs = snapshots[0]["root_pos_w"].shape[0]
         self.history = snapshots[0]["net_forces_w_history"].shape[1]
         self._stack = {
-            n: torch.stack([torch.as_tensor(s[n]) for s in snapshots], 0).to(self.device).contiguous() for n in DYNAMIC
+            n: torch.stack([torch.as_tensor(s[n]) for s in snapshots], 0).to(self.device).contiguous()
+            for n in DYNAMIC + EXTRA if n in snapshots[0]
         }
         self._static = {n: torch.as_tensor(snapshots[0][n]).to(self.device).contiguous() for n in STATIC}
         self.gravity_dir = [float(x) for x in gravity_dir]
@@ -196,4 +213,4 @@ class StateFeed:
         return d
 
     def names(self):
-        return tuple(DYNAMIC) + tuple(STATIC)
+        return tuple(self._stack) + tuple(STATIC)

@@ -47,7 +47,7 @@ from isaaclab.sensors.ray_caster.patterns import patterns as ref_patterns  # noq
 from isaaclab.terrains.height_field.utils import convert_height_field_to_mesh  # noqa: E402
 
 from isaaclab_amd.robots import ANYMAL_C, CARTPOLE, G1, RobotSpec  # noqa: E402
-from isaaclab_amd.state_feed import DYNAMIC, STATIC, StateFeed  # noqa: E402
+from isaaclab_amd.state_feed import DYNAMIC, EXTRA, STATIC, StateFeed  # noqa: E402
 from isaaclab_amd.terrain import make_rough_terrain  # noqa: E402
 from oracle.raycast import raycast_f64  # noqa: E402
 
@@ -178,6 +178,46 @@ class FakeRayCaster:
         self.data = types.SimpleNamespace(pos_w=None, quat_w=None, ray_hits_w=None)
 
 
+def make_real_ray_caster(scanner_cfg, feed: StateFeed, mesh):
+    """The REAL ``RayCaster`` (``reset``, ``_initialize_rays_impl``, ``_update_buffers_impl``, lazy ``data``) and ``SensorBase``
+    (``update``, ``_update_outdated_buffers``) over a stand-in prim view that serves the feed's root pose; only the Warp query
+    ``raycast_mesh`` is replaced (fp64 brute force, oracle/raycast_oracle.c).  Built without ``__init__`` (which needs the simulator)."""
+    import importlib
+
+    rc_mod = importlib.import_module("isaaclab.sensors.ray_caster.ray_caster")  # (the package re-exports shadow the attribute chain)
+    RayCasterData = importlib.import_module("isaaclab.sensors.ray_caster.ray_caster_data").RayCasterData
+
+    class _View:  # plays isaacsim XFormPrim: get_world_poses(env_ids) -> (pos, quat wxyz)
+        count = feed.num_envs
+
+        def get_world_poses(self, env_ids):
+            return feed["root_pos_w"][env_ids], feed["root_quat_w"][env_ids]
+
+    rc_mod.XFormPrim = _View
+
+    def fake_raycast_mesh(ray_starts, ray_directions, mesh, max_dist=1e6, **kw):
+        verts, tris = mesh
+        shape = ray_starts.shape
+        hits, _, _ = raycast_f64(verts, tris, ray_starts.reshape(-1, 3).numpy(), ray_directions.reshape(-1, 3).numpy(), max_dist=max_dist)
+        return torch.from_numpy(hits).view(shape), None, None, None
+
+    rc_mod.raycast_mesh = fake_raycast_mesh
+    N = feed.num_envs
+    s = object.__new__(rc_mod.RayCaster)
+    s.cfg = scanner_cfg
+    s._view = _View()
+    s._device = "cpu"
+    s._num_envs = N
+    s._is_visualizing = False
+    s._data = RayCasterData()
+    s.meshes = {scanner_cfg.mesh_prim_paths[0]: mesh}
+    s._timestamp = torch.zeros(N)  # SensorBase._initialize_impl (sensor_base.py)
+    s._timestamp_last_update = torch.zeros(N)
+    s._is_outdated = torch.ones(N, dtype=torch.bool)
+    s._initialize_rays_impl()
+    return s
+
+
 class FakeScene:
     def __init__(self, entities: dict, sensors: dict, env_origins, cfg):
         self._e = dict(entities)
@@ -201,8 +241,11 @@ class FakeCommandManager:
     def get_command(self, name):
         return self._feed["command"]
 
+    def get_term(self, name):  # what command_resample reads (terminations.py:41): CommandTerm.time_left / command_counter
+        return types.SimpleNamespace(time_left=self._feed["command_time_left"], command_counter=self._feed["command_counter"])
 
-def build_ref_env(env_cfg, robot: RobotSpec, feed: StateFeed):
+
+def build_ref_env(env_cfg, robot: RobotSpec, feed: StateFeed, real_scanner=None):
     N = feed.num_envs
     robot_asset = FakeArticulation(robot, feed)
     sensors = {}
@@ -214,12 +257,16 @@ def build_ref_env(env_cfg, robot: RobotSpec, feed: StateFeed):
         R = len(pc.func(pc, "cpu")[1])
         sensors["height_scanner"].data.pos_w = torch.zeros(N, 3)
         sensors["height_scanner"].data.ray_hits_w = torch.zeros(N, R, 3)
+        if real_scanner is not None:
+            sensors["height_scanner"] = real_scanner
     env = types.SimpleNamespace()
     env.num_envs = N
     env.device = "cpu"
     env.sim = types.SimpleNamespace(is_playing=lambda: True)
     env.cfg = env_cfg
     env.scene = FakeScene({"robot": robot_asset}, sensors, feed["env_origins"], env_cfg.scene)
+    env.scene.terrain = types.SimpleNamespace(cfg=env_cfg.scene.terrain)  # terrain_out_of_bounds reads scene.terrain.cfg.terrain_generator
+    env.common_step_counter = 0
     env.step_dt = env_cfg.sim.dt * env_cfg.decimation
     env.max_episode_length_s = env_cfg.episode_length_s
     env.max_episode_length = math.ceil(env_cfg.episode_length_s / env.step_dt)
@@ -268,28 +315,40 @@ def mesh_sha256(vertices, triangles) -> str:
 ROUGH_TERRAIN_ARGS = dict(num_rows=2, num_cols=3, tile=4.0, border=3.0, seed=11)  # the small terrain of the rough fixtures
 
 
-def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int, seed: int, mesh=None, extent=None):
+def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int, seed: int, mesh=None, extent=None, kitchen=None):
+    """``kitchen``: options of the kitchen-sink fixture -- ``real_scanner`` (the height scanner is the real RayCaster/SensorBase with its
+    update-period gating and drift), ``scan_ts0`` (timestamps injected after reset()), ``feed_tweak(feed)``, ``weight_change`` =
+    (step, term, weight) applied with the real ``modify_reward_weight`` curriculum term before that step."""
+    kitchen = kitchen or {}
     torch.manual_seed(seed)
     dump_cfg(task, env_cfg, agent_cfg, robot)
     feed = StateFeed(robot, N, "cpu", seed=seed, num_snapshots=steps + 1, extent_xy=extent)
-    env = build_ref_env(env_cfg, robot, feed)
+    if kitchen.get("feed_tweak"):
+        kitchen["feed_tweak"](feed)
+    scanner = make_real_ray_caster(env_cfg.scene.height_scanner, feed, mesh) if kitchen.get("real_scanner") else None
+    env = build_ref_env(env_cfg, robot, feed, real_scanner=scanner)
     has_scan = "height_scanner" in env.scene.sensors
     A = env.action_manager.total_action_dim
-    D = env.observation_manager.group_obs_dim["policy"][0]
+    om = env.observation_manager
+    group_names = list(om.group_obs_dim)
+    D0 = om.group_obs_dim[group_names[0]][0]
+    D = sum(om.group_obs_dim[g][0] for g in group_names)
     gen = torch.Generator().manual_seed(seed + 1000)
     rec: dict[str, np.ndarray] = {}
 
     def put(name, t):
         rec[name] = t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
-    meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=int(A), obs_dim=int(D),
+    meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=int(A), obs_dim=int(D0), obs_dim_total=int(D),
+                obs_groups=group_names, obs_group_dims=[int(om.group_obs_dim[g][0]) for g in group_names],
                 step_dt=env.step_dt, max_episode_length=env.max_episode_length,
                 max_episode_length_s=env.max_episode_length_s, gravity_dir=feed.gravity_dir,
                 reward_terms=env.reward_manager.active_terms, termination_terms=env.termination_manager.active_terms,
-                obs_terms=env.observation_manager.active_terms["policy"],
-                obs_term_dims=[[int(x) for x in d] for d in env.observation_manager.group_obs_term_dim["policy"]])
+                obs_terms=env.observation_manager.active_terms[group_names[0]],
+                obs_term_dims=[[int(x) for x in d] for d in env.observation_manager.group_obs_term_dim[group_names[0]]])
     for n in STATIC:
         put("static/" + n, feed[n])
+    in_names = DYNAMIC + (EXTRA if kitchen else ())
     if has_scan:
         put("mesh/vertices", mesh[0])
         put("mesh/triangles", mesh[1])
@@ -305,11 +364,15 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         # laid out per OBS COLUMN (D wide): advance `col` to each term's offset.
         u = torch.rand(N, D, generator=gen)
         put(f"{tag}/noise_u", u)
-        # term-offset bookkeeping: patch so that draw k lands on the columns of the k-th noisy term
-        dims = [d[0] for d in env.observation_manager.group_obs_term_dim["policy"]]
-        cfgs = env.observation_manager._group_obs_term_cfgs["policy"]
-        offs = np.concatenate([[0], np.cumsum(dims)])
-        noisy_offsets = [int(offs[i]) for i, c in enumerate(cfgs) if c.noise]
+        # term-offset bookkeeping: patch so that draw k lands on the columns of the k-th noisy term (groups side by side, in the
+        # order ObservationManager.compute walks them)
+        noisy_offsets, base = [], 0
+        for gname in group_names:
+            dims = [d[0] for d in om.group_obs_term_dim[gname]]
+            cfgs = om._group_obs_term_cfgs[gname]
+            offs = np.concatenate([[0], np.cumsum(dims)])
+            noisy_offsets += [base + int(offs[i]) for i, c in enumerate(cfgs) if c.noise]
+            base += int(offs[-1])
         it = iter(noisy_offsets)
 
         def rand_like_at(x, *a, **k):
@@ -318,28 +381,51 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
 
         ref_noise_model.torch.rand_like = rand_like_at  # same module object as torch; restore below
         try:
-            obs = env.observation_manager.compute()["policy"]
+            all_obs = env.observation_manager.compute()
         finally:
             torch.rand_like = real_rand_like
+        obs = all_obs[group_names[0]]
         put(f"{tag}/obs", obs)
+        for gname in group_names[1:]:
+            put(f"{tag}/obs/{gname}", all_obs[gname])
+        if scanner is not None:  # what the lazy refresh inside compute() left in the sensor
+            put(f"{tag}/sensor_pos_w", scanner._data.pos_w)
+            put(f"{tag}/ray_hits_w", scanner._data.ray_hits_w)
+            put(f"{tag}/scan_timestamp", scanner._timestamp)
+            put(f"{tag}/scan_timestamp_last_update", scanner._timestamp_last_update)
         return obs
 
     def update_scanner():
         if not has_scan:
             return
+        if scanner is not None:
+            # the hits every env WOULD get at its current pose + drift (input of the oracle's own gating; the real sensor decides
+            # by itself, lazily, inside observation_manager.compute())
+            R = scanner.num_rays
+            starts_w = ref_math.quat_apply_yaw(feed["root_quat_w"].repeat(1, R), scanner.ray_starts) + (feed["root_pos_w"] + scanner.drift).unsqueeze(1)
+            fresh, _, _ = raycast_f64(mesh[0], mesh[1], starts_w.numpy().reshape(-1, 3), scanner.ray_directions.numpy().reshape(-1, 3),
+                                      max_dist=env_cfg.scene.height_scanner.max_distance)
+            return starts_w, torch.from_numpy(fresh).view(N, R, 3)
         pos_w, quat_w, starts_w, dirs_w, hits = ref_height_scanner(env_cfg.scene.height_scanner, feed, mesh)
         s = env.scene.sensors["height_scanner"]
         s.data.pos_w, s.data.quat_w, s.data.ray_hits_w = pos_w, quat_w, hits
         return starts_w, hits
 
     # ---- reset() : ManagerBasedEnv.reset (manager_based_env.py:264-315) -> obs only
-    for n in DYNAMIC:
+    for n in in_names:
         put(f"reset/in/{n}", feed[n])
+    if scanner is not None:  # ManagerBasedEnv.reset -> _reset_idx -> scene.reset(env_ids) -> RayCaster.reset (drift drawn here)
+        scanner.reset(torch.arange(N))
+        put("reset/scan_drift", scanner.drift)
     sc = update_scanner()
     if sc is not None:
         put("reset/ray_starts_w", sc[0])
-        put("reset/ray_hits_w", sc[1])
+        put("reset/ray_hits_fresh" if scanner is not None else "reset/ray_hits_w", sc[1])
     compute_obs("reset")
+    if kitchen.get("scan_ts0") is not None:  # long-running sensors: fp32 timestamps far from zero (the state a 16 s old episode has)
+        scanner._timestamp[:] = kitchen["scan_ts0"]
+        scanner._timestamp_last_update[:] = kitchen["scan_ts0"]
+        put("reset/scan_ts0", scanner._timestamp)
     # random episode lengths (RSL-RL init_at_random_ep_len) incl. some that time out on step 1..steps
     ep = torch.randint(0, env.max_episode_length, (N,), generator=gen)
     ep[::17] = env.max_episode_length - 1
@@ -351,6 +437,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         tag = f"step{t}"
         action = (torch.randn(N, A, generator=gen)).clamp(-3, 3)
         put(f"{tag}/action", action)
+        for wc in kitchen.get("weight_changes", ()):
+            if wc[0] == t:  # CurriculumManager term (envs/mdp/curriculums.py:20-37), the REAL function
+                from isaaclab.envs.mdp.curriculums import modify_reward_weight
+
+                env.common_step_counter = 10
+                modify_reward_weight(env, torch.arange(N), term_name=wc[1], weight=wc[2], num_steps=5)
         # -- pre-physics
         env.action_manager.process_action(action)
         term0 = next(iter(env.action_manager._terms.values()))
@@ -358,12 +450,16 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         put(f"{tag}/prev_action", env.action_manager.prev_action)
         # -- physics: feed moves to the next snapshot
         feed.advance()
-        for n in DYNAMIC:
+        for n in in_names:
             put(f"{tag}/in/{n}", feed[n])
-        sc = update_scanner()  # RayCaster is lazy; pose does not change on reset in the feed
-        if sc is not None:
-            put(f"{tag}/ray_starts_w", sc[0])
-            put(f"{tag}/ray_hits_w", sc[1])
+        if scanner is not None:  # scene.update(physics_dt) inside the decimation loop (manager_based_rl_env.py:185-196)
+            for _ in range(env_cfg.decimation):
+                scanner.update(env_cfg.sim.dt)
+        else:
+            sc = update_scanner()  # RayCaster is lazy; pose does not change on reset in the feed
+            if sc is not None:
+                put(f"{tag}/ray_starts_w", sc[0])
+                put(f"{tag}/ray_hits_w", sc[1])
         # -- post-physics (manager_based_rl_env.py:200-239)
         env.episode_length_buf += 1
         reset_buf = env.termination_manager.compute()
@@ -386,6 +482,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
             log.update(env.reward_manager.reset(reset_env_ids))
             log.update(env.termination_manager.reset(reset_env_ids))
             env.episode_length_buf[reset_env_ids] = 0
+            if scanner is not None:  # _reset_idx -> scene.reset(env_ids)
+                scanner.reset(reset_env_ids)
+        if scanner is not None:
+            put(f"{tag}/scan_drift", scanner.drift)
+            sc = update_scanner()
+            put(f"{tag}/ray_hits_fresh", sc[1])
         rec[f"{tag}/log_json"] = np.array(json.dumps({k: float(v) for k, v in log.items()}))
         for name in env.reward_manager.active_terms:
             put(f"{tag}/episode_sums/{name}", env.reward_manager._episode_sums[name])
@@ -394,6 +496,9 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         put(f"{tag}/prev_action_after_reset", env.action_manager.prev_action)
         compute_obs(tag)
 
+    if kitchen:
+        meta["weight_changes"] = [list(w) for w in kitchen.get("weight_changes", ())]
+        meta["real_scanner"] = bool(kitchen.get("real_scanner"))
     rec["meta_json"] = np.array(json.dumps(meta))
     os.makedirs(GOLDEN, exist_ok=True)
     np.savez_compressed(os.path.join(GOLDEN, task + ".npz"), **rec)
@@ -438,6 +543,93 @@ def mesh_fixture():
                         t_thr=t1.astype(np.int64), grid_xy_starts=s.numpy(), grid_xy_dirs=d.numpy(),
                         grid_yx_starts=s2.numpy(), grid_yx_dirs=d2.numpy())
     print("[golden] hf_mesh + grid_pattern", s.shape, s2.shape)
+
+
+KITCHEN = "Isaac-Velocity-Rough-Anymal-C-v0-kitchen"
+
+
+def kitchen_cfg():
+    """The rough Anymal-C task with every remaining op of isaaclab.envs.mdp on top (SURVEY.md 8a "also present" rows): the cheap
+    observation terms, the optional reward and termination terms, a second ("critic") observation group that scans the same height
+    scanner, and a scanner with a drift range (its update period stays the task's 0.02 s)."""
+    import isaaclab.envs.mdp as mdp
+    import isaaclab_tasks.manager_based.locomotion.velocity.mdp as vel_mdp
+    from isaaclab.managers import ObservationGroupCfg, ObservationTermCfg as Obs, RewardTermCfg as Rew, SceneEntityCfg
+    from isaaclab.managers import TerminationTermCfg as Done
+    from isaaclab.utils.noise import AdditiveUniformNoiseCfg as Unoise
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.rough_env_cfg import AnymalCRoughEnvCfg
+
+    cfg = AnymalCRoughEnvCfg()
+    robot = lambda **kw: SceneEntityCfg("robot", **kw)  # noqa: E731
+    pol = cfg.observations.policy
+    pol.base_pos_z = Obs(func=mdp.base_pos_z, noise=Unoise(n_min=-0.01, n_max=0.01))
+    pol.root_pos = Obs(func=mdp.root_pos_w)
+    pol.root_quat_unique = Obs(func=mdp.root_quat_w, params={"make_quat_unique": True})
+    pol.root_lin_vel_w = Obs(func=mdp.root_lin_vel_w, noise=Unoise(n_min=-0.05, n_max=0.05), clip=(-1.0, 1.0))
+    pol.root_ang_vel_w = Obs(func=mdp.root_ang_vel_w, scale=0.25)
+    pol.haa_pos = Obs(func=mdp.joint_pos, params={"asset_cfg": robot(joint_names=[".*HAA"])})
+    pol.joint_vel_abs = Obs(func=mdp.joint_vel)
+    pol.kfe_pos_norm = Obs(func=mdp.joint_pos_limit_normalized, params={"asset_cfg": robot(joint_names=[".*KFE"])},
+                           noise=Unoise(n_min=-0.02, n_max=0.02))
+
+    critic = ObservationGroupCfg()
+    critic.enable_corruption = False
+    critic.concatenate_terms = True
+    critic.base_lin_vel = Obs(func=mdp.base_lin_vel, noise=Unoise(n_min=-0.1, n_max=0.1))  # noise dropped: corruption is off
+    critic.base_ang_vel = Obs(func=mdp.base_ang_vel)
+    critic.projected_gravity = Obs(func=mdp.projected_gravity)
+    critic.velocity_commands = Obs(func=mdp.generated_commands, params={"command_name": "base_velocity"})
+    critic.joint_pos = Obs(func=mdp.joint_pos_rel)
+    critic.joint_vel = Obs(func=mdp.joint_vel_rel, scale=0.05)
+    critic.actions = Obs(func=mdp.last_action)
+    critic.height_scan = Obs(func=mdp.height_scan, params={"sensor_cfg": SceneEntityCfg("height_scanner"), "offset": 0.3}, clip=(-2.0, 2.0))
+    critic.root_quat = Obs(func=mdp.root_quat_w)
+    cfg.observations.critic = critic
+
+    rew = cfg.rewards
+    rew.dof_pos_limits.weight = -1.0  # a zero-weight term of the task switched on; flat_orientation_l2 stays at 0 (skipped)
+    rew.alive = Rew(func=mdp.is_alive, weight=0.3)
+    rew.terminating = Rew(func=mdp.is_terminated, weight=-2.0)
+    rew.termination_kinds = Rew(func=mdp.is_terminated_term, weight=-3.0, params={"term_keys": ["base_contact", "bad_orient.*"]})
+    rew.base_height = Rew(func=mdp.base_height_l2, weight=-1.0, params={"target_height": 0.6})
+    rew.body_acc = Rew(func=mdp.body_lin_acc_l2, weight=-1.0e-3, params={"asset_cfg": robot(body_names=".*SHANK")})
+    rew.hfe_vel_l2 = Rew(func=mdp.joint_vel_l2, weight=-1.0e-3, params={"asset_cfg": robot(joint_names=".*HFE")})
+    rew.joint_vel_l1 = Rew(func=mdp.joint_vel_l1, weight=-1.0e-3, params={"asset_cfg": robot()})
+    rew.haa_deviation = Rew(func=mdp.joint_deviation_l1, weight=-0.05, params={"asset_cfg": robot(joint_names=".*HAA")})
+    rew.vel_limits = Rew(func=mdp.joint_vel_limits, weight=-0.5, params={"soft_ratio": 0.9})
+    rew.torque_limits = Rew(func=mdp.applied_torque_limits, weight=-0.01)
+    rew.action_l2 = Rew(func=mdp.action_l2, weight=-0.005)
+    rew.thigh_forces = Rew(func=mdp.contact_forces, weight=-0.02,
+                           params={"sensor_cfg": SceneEntityCfg("contact_forces", body_names=".*THIGH"), "threshold": 5.0})
+
+    term = cfg.terminations
+    term.bad_orientation = Done(func=mdp.bad_orientation, params={"limit_angle": 0.4})
+    term.too_low = Done(func=mdp.root_height_below_minimum, params={"minimum_height": 0.54})
+    term.haa_vel_limit = Done(func=mdp.joint_vel_out_of_limit, params={"asset_cfg": robot(joint_names="LF_HAA")})
+    term.kfe_vel_manual = Done(func=mdp.joint_vel_out_of_manual_limit,
+                               params={"max_velocity": 2.5, "asset_cfg": robot(joint_names=["RH_KFE", "LH_KFE"])})
+    term.effort_limit = Done(func=mdp.joint_effort_out_of_limit, params={"asset_cfg": robot(joint_names="LF_HFE")})
+    term.out_of_bounds = Done(func=vel_mdp.terrain_out_of_bounds, params={"distance_buffer": 57.0}, time_out=True)
+    term.cmd_resample = Done(func=mdp.command_resample, params={"command_name": "base_velocity", "num_resamples": 1}, time_out=True)
+
+    cfg.scene.height_scanner.drift_range = (-0.03, 0.03)
+    return cfg
+
+
+def kitchen_feed_tweak(feed: StateFeed):
+    """Make the synthetic feed exercise the added ops: quaternions with a negative real part (quat_unique), one joint whose applied
+    torque mostly differs from the computed one (joint_effort_out_of_limit is `any(isclose(computed, applied))`), incl. pairs just
+    inside / outside torch.isclose's tolerance."""
+    q = feed._stack["root_quat_w"]
+    q[:, ::5] = -q[:, ::5]
+    j = feed.robot.joint_names.index("LF_HFE")
+    a, c = feed._stack["applied_torque"], feed._stack["computed_torque"]
+    N = feed.num_envs
+    a[:, :, j] = c[:, :, j] + 1.0
+    a[:, 3::17, j] = c[:, 3::17, j]                       # exactly equal
+    a[:, 5::19, j] = c[:, 5::19, j] * (1.0 + 0.9e-5)      # inside rtol 1e-5 (for |c| not tiny)
+    a[:, 7::23, j] = c[:, 7::23, j] * (1.0 + 1.3e-5)      # outside
+    assert N >= 24
 
 
 def main():
@@ -492,6 +684,12 @@ def main():
     if want("Isaac-Velocity-Rough-Anymal-C-v0"):
         run_task("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64,
                  steps=3, seed=103, mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))
+    if want(KITCHEN):
+        ts0 = torch.tensor([0.0, 16.5, 30.0, 5.0]).repeat(16)  # fp32 timestamps of fresh, 16 s, 30 s and 5 s old sensors
+        run_task(KITCHEN, kitchen_cfg(), AnymalCRoughPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=107, mesh=mesh,
+                 extent=(ext[0] - 1.0, ext[1] - 1.0),
+                 kitchen=dict(real_scanner=True, scan_ts0=ts0, feed_tweak=kitchen_feed_tweak,
+                              weight_changes=[(2, "action_l2", -0.02), (3, "flat_orientation_l2", -1.5), (4, "alive", 0.0)]))
     if want("Isaac-Velocity-Rough-G1-v0"):
         run_task("Isaac-Velocity-Rough-G1-v0", G1RoughEnvCfg(), G1RoughPPORunnerCfg(), G1, N=64, steps=3, seed=104,
                  mesh=mesh, extent=(ext[0] - 1.0, ext[1] - 1.0))

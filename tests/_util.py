@@ -10,7 +10,7 @@ import torch
 
 from isaaclab_amd.env import load_task_cfg
 from isaaclab_amd.robots import ROBOTS
-from isaaclab_amd.state_feed import DYNAMIC, STATIC, StateFeed
+from isaaclab_amd.state_feed import DYNAMIC, EXTRA, STATIC, StateFeed
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TASKS = ("Isaac-Cartpole-v0", "Isaac-Velocity-Flat-Anymal-C-v0", "Isaac-Velocity-Flat-Anymal-C-v0-hist3", "Isaac-Velocity-Flat-Anymal-C-v0-mod",
@@ -36,7 +36,7 @@ class Golden:
         """snapshot 0 = state at reset(), snapshot k+1 = state after physics of step k"""
         out = []
         for tag in ["reset"] + [f"step{k}" for k in range(self.steps)]:
-            d = {n: self.t(f"{tag}/in/{n}") for n in DYNAMIC}
+            d = {n: self.t(f"{tag}/in/{n}") for n in DYNAMIC + EXTRA if f"{tag}/in/{n}" in self.z}
             d.update({n: self.t(f"static/{n}") for n in STATIC})
             out.append(d)
         return out
@@ -64,3 +64,10 @@ def assert_close(a, b, tol=FLOAT_TOL, what=""):
     lim = tol * torch.clamp(b[fin].abs(), min=1.0)
     bad = err > lim
     assert not bad.any(), f"{what}: max err {err.max().item():.3e} (tol {tol}), {int(bad.sum())} elements over"
+
+KITCHEN = "Isaac-Velocity-Rough-Anymal-C-v0-kitchen"  # every remaining isaaclab.envs.mdp op + a "critic" group + the scanner as a SensorBase
+
+
+def set_reward_weight(cfg_env: dict, term: str, weight: float):
+    """What the reference's ``modify_reward_weight`` curriculum term does to the manager's term cfg (envs/mdp/curriculums.py:20-37)."""
+    cfg_env["rewards"][term]["weight"] = weight

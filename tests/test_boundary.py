@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from _util import TASKS
+from _util import KITCHEN, TASKS
 from isaaclab_amd import _lib, plan as planmod
 from isaaclab_amd.env import load_task_cfg
 from isaaclab_amd.robots import ROBOTS
@@ -68,7 +68,7 @@ def test_header_constants_match_plan_compiler():
         assert tuple(names) == tuple(fields), struct
 
 
-@pytest.mark.parametrize("task", TASKS)
+@pytest.mark.parametrize("task", TASKS + (KITCHEN,))
 def test_plan_blob_validates_through_the_c_abi(libimx, task):
     fx = load_task_cfg(task)
     p = planmod.compile_plan(fx["env"], ROBOTS[fx["robot"]])
@@ -78,6 +78,30 @@ def test_plan_blob_validates_through_the_c_abi(libimx, task):
     assert rc == 0, libimx.imx_last_error()
     assert libimx.imx_plan_obs_dim(h) == p.obs_dim
     assert libimx.imx_plan_scratch_bytes(h, 4096) > 0
+    libimx.imx_plan_destroy(h)
+
+
+def test_plan_update_in_place_accepts_same_shape_only(libimx):
+    """imx_plan_update = RewardManager/TerminationManager.set_term_cfg: a recompiled blob of the same shape replaces the tables, a
+    different shape (another observation width) is refused."""
+    import copy
+
+    fx = load_task_cfg("Isaac-Velocity-Flat-Anymal-C-v0")
+    robot = ROBOTS[fx["robot"]]
+    p = planmod.compile_plan(fx["env"], robot)
+    blob = np.ascontiguousarray(p.blob, np.int32)
+    h = ctypes.c_void_p()
+    assert libimx.imx_plan_create(blob.ctypes.data, blob.size, ctypes.byref(h)) == 0
+    cfg = copy.deepcopy(fx["env"])
+    cfg["rewards"]["flat_orientation_l2"]["weight"] = 0.0  # non-zero -> zero: same shape in plan v3
+    cfg["rewards"]["dof_pos_limits"]["weight"] = -1.0      # zero -> non-zero
+    cfg["terminations"]["base_contact"]["params"]["threshold"] = 2.0
+    b2 = np.ascontiguousarray(planmod.compile_plan(cfg, robot).blob, np.int32)
+    assert b2.size == blob.size
+    assert libimx.imx_plan_update(h, b2.ctypes.data, b2.size, None) == 0, libimx.imx_last_error()
+    del cfg["observations"]["policy"]["actions"]
+    b3 = np.ascontiguousarray(planmod.compile_plan(cfg, robot).blob, np.int32)
+    assert libimx.imx_plan_update(h, b3.ctypes.data, b3.size, None) != 0 and b"different shape" in libimx.imx_last_error()
     libimx.imx_plan_destroy(h)
 
 

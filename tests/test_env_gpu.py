@@ -340,3 +340,172 @@ def test_frame_table_from_the_step_kernel_equals_k_frame():
         obs = env.step(g.t(f"step{k}/action").cuda())[0]["policy"].clone()  # frame written by the step kernel
         again = env._compute_observations().clone()                          # k_frame on the same state
         assert torch.equal(obs, again)
+
+
+def test_kitchen_sink_matches_reference_golden():
+    """Every remaining op of isaaclab.envs.mdp (SURVEY 8a "also present" rows: base_pos_z, root_*_w, joint_pos, joint_vel,
+    joint_pos_limit_normalized; base_height_l2, body_lin_acc_l2, joint_vel_l2, joint_vel_limits, applied_torque_limits, action_l2,
+    contact_forces, is_alive, is_terminated, is_terminated_term; bad_orientation, root_height_below_minimum, joint_vel_out_of_limit,
+    joint_vel_out_of_manual_limit, joint_effort_out_of_limit, terrain_out_of_bounds, command_resample), a second observation group
+    ("critic") scanning the same sensor, the height scanner's SensorBase gating (16 s old fp32 timestamps skip updates) and drift, and
+    reward weights re-installed through get_term_cfg / set_term_cfg mid-run -- against the fixture the REAL reference produced."""
+    from _util import KITCHEN
+
+    g = Golden(KITCHEN)
+    env = make_env(g)
+    env.materialize_ray_hits = True
+    N = g.N
+    Dp, Dc = g.meta["obs_group_dims"]
+    assert env.observation_manager.group_obs_dim == {"policy": (Dp,), "critic": (Dc,)}
+    assert env.plan.scan_stateful
+    env._noise_u = g.t("reset/noise_u").cuda()
+    env._scan_drift_feed = g.t("reset/scan_drift").cuda()
+    env.scanner_keep_all_hits = True  # the timestamps are overwritten below: the kernel cannot foresee which envs will skip step 0
+    obs_dict, _ = env.reset()
+    env.scanner_keep_all_hits = False
+    assert_close(obs_dict["policy"], g.t("reset/obs"), FLOAT_TOL, "reset obs")
+    assert_close(obs_dict["critic"], g.t("reset/obs/critic"), FLOAT_TOL, "reset critic obs")
+    assert_close(env._ray_hits, g.t("reset/ray_hits_w"), FLOAT_TOL, "reset sensor hits")
+    # sensors that have been running for 0 / 16.5 / 30 / 5 s (fp32 timestamps): inject like the fixture generator did
+    env._scan_state[:, :, 0] = g.t("reset/scan_ts0").cuda()
+    env._scan_state[:, :, 1] = g.t("reset/scan_ts0").cuda()
+    env.episode_length_buf = g.t("reset/episode_length_buf")
+    stale = 0
+    for k in range(g.steps):
+        tag = f"step{k}"
+        for wc in g.meta["weight_changes"]:
+            if wc[0] == k:  # envs/mdp/curriculums.py:32-36
+                term_cfg = env.reward_manager.get_term_cfg(wc[1])
+                term_cfg.weight = wc[2]
+                env.reward_manager.set_term_cfg(wc[1], term_cfg)
+        env._noise_u.copy_(g.t(f"{tag}/noise_u"))
+        env._scan_drift_feed.copy_(g.t(f"{tag}/scan_drift"))
+        obs_dict, rew, terminated, time_outs, extras = env.step(g.t(f"{tag}/action").cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(terminated.cpu(), g.t(f"{tag}/terminated")) and torch.equal(time_outs.cpu(), g.t(f"{tag}/time_outs"))
+        assert torch.equal(env.reset_env_ids.cpu(), g.t(f"{tag}/reset_env_ids"))
+        for name in g.meta["termination_terms"]:
+            assert torch.equal(env.termination_manager.get_term(name).cpu(), g.t(f"{tag}/term_dones/{name}")), name
+        assert torch.equal(env.episode_length_buf.cpu(), g.t(f"{tag}/episode_length_buf"))
+        assert_close(rew, g.t(f"{tag}/reward"), FLOAT_TOL, "reward")
+        assert_close(env.reward_manager._step_reward, g.t(f"{tag}/step_reward"), FLOAT_TOL, "step_reward")
+        for name in g.meta["reward_terms"]:
+            assert_close(env.reward_manager._episode_sums[name], g.t(f"{tag}/episode_sums/{name}"), FLOAT_TOL, name)
+        # the sensor: which envs refreshed (timestamps bit-exact), what they hold
+        cur = env._scan_state[(int(env._counters[2].item()) + 1) & 1].cpu()
+        assert torch.equal(cur[:, 0], g.t(f"{tag}/scan_timestamp")), "sensor timestamps"
+        assert torch.equal(cur[:, 1], g.t(f"{tag}/scan_timestamp_last_update")), "sensor last-update stamps"
+        stale += int((cur[:, 0] != cur[:, 1]).sum())
+        assert_close(cur[:, 5], g.t(f"{tag}/sensor_pos_w")[:, 2], 1e-6, "sensor data.pos_w z")
+        assert_close(env._ray_hits[..., 2], g.t(f"{tag}/ray_hits_w")[..., 2], FLOAT_TOL, "sensor hit heights (stale rows keep the old cast)")
+        assert_close(obs_dict["policy"], g.t(f"{tag}/obs"), FLOAT_TOL, "obs")
+        assert_close(obs_dict["critic"], g.t(f"{tag}/obs/critic"), FLOAT_TOL, "critic obs")
+        for key, v in g.log(k).items():
+            got = float(extras["log"][key])
+            assert abs(got - v) <= FLOAT_TOL * max(1.0, abs(v)), (key, got, v)
+    assert stale > 10
+    assert env.reward_manager.get_term_cfg("action_l2").weight == -0.02
+    with pytest.raises(ValueError):
+        env.reward_manager.set_term_cfg("no_such_term", None)
+    env.close()
+
+
+# ---- Python-evaluated ("EXTERNAL") terms: user functions the term compiler does not know (ManagerBase term contract,
+# managers/manager_base.py:278-395: func(env, **params) -> Tensor[N, ...], SceneEntityCfg parameters resolved)
+def _user_reward(env, asset_cfg, gain: float):
+    return gain * torch.sum(torch.abs(env.scene["robot"].data.joint_vel[:, asset_cfg.joint_ids]), dim=1)
+
+
+def _user_termination(env, limit: float):
+    return env.scene["robot"].data.root_lin_vel_b[:, 0] > limit
+
+
+def _user_obs(env, asset_cfg):
+    d = env.scene["robot"].data
+    return torch.cat([d.joint_pos[:, asset_cfg.joint_ids] ** 2, d.projected_gravity_b[:, 2:3]], dim=1)
+
+
+def _user_modifier(x, gain: float):
+    return x * gain + 1.0
+
+
+def test_python_evaluated_terms_step_end_to_end():
+    """One reward, one termination and one observation term the compiler does not know are routed to IMX_*_EXTERNAL, evaluated by
+    calling the Python function each step, and folded into the fused kernels (weighting, reset bookkeeping, noise / clip / scale).
+    Checked against the CPU oracle with the same three functions written as oracle terms."""
+    import copy
+
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from oracle.mdp_oracle import OracleEnv
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    fx = copy.deepcopy(g.fixture)
+    ent = {"name": "robot", "joint_names": [".*KFE"], "joint_ids": "slice(None, None, None)", "body_names": None, "body_ids": "slice(None, None, None)",
+           "preserve_order": False}
+    fx["env"]["rewards"]["user_rew"] = {"func": _user_reward, "params": {"asset_cfg": ent, "gain": 0.5}, "weight": -0.25}
+    fx["env"]["terminations"]["user_term"] = {"func": _user_termination, "params": {"limit": 0.9}, "time_out": False}
+    fx["env"]["observations"]["policy"]["user_obs"] = {
+        "func": _user_obs, "params": {"asset_cfg": ent}, "_dim": 5, "noise": {"func": "isaaclab.utils.noise.noise_model:uniform_noise",
+        "n_min": -0.1, "n_max": 0.1, "operation": "add"}, "clip": [-0.5, 2.0], "scale": 2.0,
+        "modifiers": [{"func": _user_modifier, "params": {"gain": 0.5}}]}
+    env = ManagerBasedRLEnv(fx, state_feed=g.feed("cuda:0"))
+    assert (env.plan.n_ext_rew, env.plan.n_ext_term, env.plan.n_ext_obs) == (1, 1, 5)
+    D = env.plan.obs_dim
+    assert D == g.meta["obs_dim"] + 5
+
+    class Orc(OracleEnv):  # the same three user terms on the CPU side (the oracle keys terms on "module:function" strings)
+        kfe = [i for i, n in enumerate(g.robot.joint_names) if n.endswith("KFE")]
+
+        def _reward(self, fn, p):
+            if fn.endswith(":_user_reward"):
+                return p["gain"] * torch.sum(torch.abs(self.state("joint_vel")[:, self.kfe]), dim=1)
+            return super()._reward(fn, p)
+
+        def _termination(self, fn, p):
+            if fn.endswith(":_user_termination"):
+                return self.root_lin_vel_b[:, 0] > p["limit"]
+            return super()._termination(fn, p)
+
+        def _obs_term(self, fn, p):
+            if fn.endswith(":_user_obs"):
+                return torch.cat([self.state("joint_pos")[:, self.kfe] ** 2, self.projected_gravity_b[:, 2:3]], dim=1)
+            return super()._obs_term(fn, p)
+
+        def _modifier(self, term, idx, m, obs):
+            if m["func"].endswith(":_user_modifier"):
+                return _user_modifier(obs, **m["params"])
+            return super()._modifier(term, idx, m, obs)
+
+    cpu_feed = g.feed("cpu")
+    fo = copy.deepcopy(fx["env"])
+    fo["rewards"]["user_rew"]["func"] = "user:_user_reward"
+    fo["terminations"]["user_term"]["func"] = "user:_user_termination"
+    fo["observations"]["policy"]["user_obs"]["func"] = "user:_user_obs"
+    fo["observations"]["policy"]["user_obs"]["modifiers"][0]["func"] = "user:_user_modifier"
+    orc = Orc(fo, g.robot.joint_names, g.robot.body_names, g.N, cpu_feed.__getitem__, g.meta["gravity_dir"])
+    gen = torch.Generator().manual_seed(5)
+    u = torch.rand(g.N, D, generator=gen)
+    env._noise_u = u.cuda()
+    obs, _ = env.reset()
+    assert_close(obs["policy"], orc.compute_observations(u), FLOAT_TOL, "reset obs with a Python-evaluated term")
+    ep = g.t("reset/episode_length_buf")
+    env.episode_length_buf = ep
+    orc.episode_length_buf[:] = ep
+    fired = 0
+    for k in range(g.steps):
+        a = g.t(f"step{k}/action")
+        u = torch.rand(g.N, D, generator=gen)
+        env._noise_u.copy_(u)
+        obs, rew, term, tout, _ = env.step(a.cuda())
+        orc.process_action(a)
+        cpu_feed.advance()
+        out = orc.post_physics_step(u)
+        assert torch.equal(term.cpu(), out["terminated"]) and torch.equal(env.reset_env_ids.cpu(), out["reset_env_ids"])
+        assert torch.equal(env.termination_manager.get_term("user_term").cpu(), orc.term_dones["user_term"])
+        fired += int(orc.term_dones["user_term"].sum())
+        assert_close(rew, out["reward"], FLOAT_TOL, "reward")
+        assert_close(env.reward_manager._episode_sums["user_rew"], orc.episode_sums["user_rew"], FLOAT_TOL, "episode sum of the user reward")
+        assert_close(obs["policy"], out["obs"], FLOAT_TOL, "obs")
+    assert fired > 0 and float(orc.episode_sums["user_rew"].abs().sum()) > 0
+    env.close()
+

@@ -128,3 +128,74 @@ def test_rough_fixture_mesh_is_the_generator_mesh_at_head(task):
     assert sha(v2, t2) == g.meta["mesh_sha256"], "terrain generator changed: re-run oracle/gen_golden.py for the rough tasks"
     # the small terrain must contain box-primitive (general) cells as well as height-field (lattice) cells
     assert len(t) < 2 * 81 * 81 * 6, "expected a mixed mesh, not six all-height-field tiles"
+
+
+def test_oracle_matches_reference_kitchen_sink():
+    """The kitchen-sink fixture (oracle/gen_golden.py::kitchen_cfg, generated by the REAL managers, terms, RayCaster/SensorBase and
+    the real ``modify_reward_weight``): every op of isaaclab.envs.mdp the four task configs do not use, two observation groups, the
+    height scanner's update-period gating (fp32 timestamps of 16 s old sensors skip updates) and drift, reward weights changed
+    mid-run."""
+    import copy
+
+    from _util import KITCHEN, set_reward_weight
+    from oracle.mdp_oracle import OracleScanner
+
+    g = Golden(KITCHEN)
+    assert g.meta["real_scanner"] and g.meta["obs_groups"] == ["policy", "critic"]
+    feed = g.feed()
+    cfg_env = copy.deepcopy(g.fixture["env"])
+    env = OracleEnv(cfg_env, g.robot.joint_names, g.robot.body_names, g.N, feed.__getitem__, gravity_dir=g.meta["gravity_dir"])
+    sc_cfg = cfg_env["scene"]["height_scanner"]
+    R = g.t("reset/ray_hits_fresh").shape[1]
+    scan = OracleScanner(g.N, R, sc_cfg["update_period"], tuple(sc_cfg["drift_range"]))
+
+    def refresh(tag):
+        scan.refresh(feed["root_pos_w"], g.t(f"{tag}/ray_hits_fresh"))
+        env.ray_hits_w, env.sensor_pos_w = scan.ray_hits_w, scan.pos_w
+        assert torch.equal(scan.pos_w, g.t(f"{tag}/sensor_pos_w")), tag
+        # the same rows were refreshed (1e-6: torch's vectorised sin/cos of yaw_quat differ in the last bit between the all-env batch the
+        # "fresh" hits were cast with and the outdated-env subset the real sensor cast)
+        assert_close(scan.ray_hits_w, g.t(f"{tag}/ray_hits_w"), 1e-6, f"{tag} sensor hits")
+        assert torch.equal(scan.timestamp, g.t(f"{tag}/scan_timestamp")) and torch.equal(scan.timestamp_last_update, g.t(f"{tag}/scan_timestamp_last_update"))
+
+    scan.reset(None, drift=g.t("reset/scan_drift"))
+    refresh("reset")
+    obs = env.compute_observation_groups(g.t("reset/noise_u"))
+    assert_close(obs["policy"], g.t("reset/obs"), 1e-6, "reset obs")
+    assert_close(obs["critic"], g.t("reset/obs/critic"), 1e-6, "reset critic obs")
+    scan.timestamp[:] = g.t("reset/scan_ts0")
+    scan.timestamp_last_update[:] = g.t("reset/scan_ts0")
+    env.episode_length_buf[:] = g.t("reset/episode_length_buf")
+    stale_seen = 0
+    for k in range(g.steps):
+        tag = f"step{k}"
+        for wc in g.meta["weight_changes"]:
+            if wc[0] == k:
+                set_reward_weight(cfg_env, wc[1], wc[2])
+        env.process_action(g.t(f"{tag}/action"))
+        feed.advance()
+        for _ in range(cfg_env["decimation"]):  # scene.update(physics_dt) in the decimation loop
+            scan.update(cfg_env["sim"]["dt"])
+
+        def after_reset(reset_env_ids, tag=tag):
+            if len(reset_env_ids) > 0:
+                scan.reset(reset_env_ids, drift=g.t(f"{tag}/scan_drift"))
+            refresh(tag)
+
+        env.pre_obs_hook = after_reset
+        out = env.post_physics_step(g.t(f"{tag}/noise_u"))
+        stale_seen += int((scan.timestamp != scan.timestamp_last_update).sum())
+        assert torch.equal(out["reset_buf"], g.t(f"{tag}/reset_buf"))
+        assert torch.equal(out["terminated"], g.t(f"{tag}/terminated")) and torch.equal(out["time_outs"], g.t(f"{tag}/time_outs"))
+        assert torch.equal(out["reset_env_ids"], g.t(f"{tag}/reset_env_ids"))
+        for name in g.meta["termination_terms"]:
+            assert torch.equal(env.term_dones[name], g.t(f"{tag}/term_dones/{name}")), name
+        assert_close(out["reward"], g.t(f"{tag}/reward"), 1e-6, "reward")
+        assert_close(out["step_reward"], g.t(f"{tag}/step_reward"), 1e-6, "step_reward")
+        for name in g.meta["reward_terms"]:
+            assert_close(env.episode_sums[name], g.t(f"{tag}/episode_sums/{name}"), 1e-6, f"episode_sums/{name}")
+        assert_close(out["obs_groups"]["policy"], g.t(f"{tag}/obs"), 1e-6, "obs")
+        assert_close(out["obs_groups"]["critic"], g.t(f"{tag}/obs/critic"), 1e-6, "critic obs")
+        for key, v in g.log(k).items():
+            assert abs(out["log"][key] - v) <= 1e-6 * max(1.0, abs(v)), key
+    assert stale_seen > 10  # the fixture really exercises skipped sensor updates

@@ -87,8 +87,11 @@ def test_term_compiler_errors_follow_the_reference():
     cfg["rewards"]["custom"] = {"func": "my_pkg.mdp:my_reward", "params": {}, "weight": 1.0}
     p = planmod.compile_plan(cfg, g.robot)
     assert p.n_ext_rew == 1 and p.reward_terms[-1].external == "my_pkg.mdp:my_reward"
-    # zero-weight terms keep their slot but emit no record (reward_manager.py:145)
-    assert p.blob[planmod.H["NREW"]] == len([t for t in p.reward_terms if t.weight != 0.0])
+    # zero-weight terms keep their slot AND their record (plan v3): the kernel skips them at run time (reward_manager.py:145) and
+    # set_term_cfg can switch them on without changing the plan's shape
+    assert p.blob[planmod.H["NREW"]] == p.blob[planmod.H["NREW_ALL"]] == len(p.reward_terms)
+    zero = [i for i, t in enumerate(p.reward_terms) if t.weight == 0.0]
+    assert zero and all(p.blob[p.blob[planmod.H["REW_OFF"]] + i * planmod.REC_WORDS + planmod.R["WEIGHT"]] == 0 for i in zero)
 
 
 def test_observation_modifiers_compile_to_programs_and_the_library_validates_them():
@@ -130,9 +133,18 @@ def test_observation_modifiers_compile_to_programs_and_the_library_validates_the
     cfg = copy.deepcopy(g.fixture["env"])
     cfg["observations"]["policy"]["joint_vel"]["modifiers"] = [{"func": "my_pkg.mods:wobble", "params": {}}]
     with pytest.raises(NotImplementedError, match="_dim"):
-        planmod.compile_plan(cfg, g.robot)  # unknown modifier: the term would have to be evaluated in Python
+        planmod.compile_plan(cfg, g.robot)  # unknown modifier: the term (function + modifier chain) has to be evaluated in Python
     cfg["observations"]["policy"]["joint_vel"]["_dim"] = 12
-    assert planmod.compile_plan(cfg, g.robot).n_ext_obs == 12
+    p2 = planmod.compile_plan(cfg, g.robot)
+    t = [t for t in p2.obs_terms if t.name == "joint_vel"][0]
+    assert p2.n_ext_obs == 12 and t.external is not None and [m[0] for m in t.py_modifiers] == ["my_pkg.mods:wobble"]
+    cfg["observations"]["policy"]["joint_vel"]["modifiers"].append({"func": "isaaclab.utils.modifiers.modifier:DigitalFilter", "A": [0.0], "B": [1.0]})
+    with pytest.raises(NotImplementedError, match="class-based"):
+        planmod.compile_plan(cfg, g.robot)  # a stateful modifier class behind a foreign one cannot run anywhere
+    cfg = copy.deepcopy(g.fixture["env"])
+    cfg["observations"]["policy"]["joint_vel"]["noise"] = {"func": "isaaclab.utils.noise.noise_model:gaussian_noise", "mean": 0.0, "std": 1.0, "operation": "add"}
+    with pytest.raises(NotImplementedError, match="noise model"):
+        planmod.compile_plan(cfg, g.robot)  # never dropped silently
 
 
 def test_policy_is_exportable_like_the_reference_exporter(tmp_path):
