@@ -209,9 +209,11 @@ typedef struct imx_buffers {
     float* obs_extra1;           /* (N,D_1) second observation group (e.g. "critic"); NULL when the plan has one group */
     float* obs_extra2;           /* (N,D_2) */
     float* obs_extra3;           /* (N,D_3) */
-    float* scan_state;           /* (2,N,8) double-buffered [timestamp, timestamp_last_update, drift xyz, data.pos_w z, outdated, -]
-                                    of the height scanner; required when IMX_H_SCAN_STATEFUL; the caller starts it with zeros and
-                                    outdated = 1 (sensors start outdated, sensor_base.py _initialize_impl) */
+    float* scan_state;           /* (N,8) [timestamp, timestamp_last_update, drift xyz, data.pos_w z, outdated, step stamp] of the
+                                    height scanner; required when IMX_H_SCAN_STATEFUL; the caller starts it with zeros and
+                                    outdated = 1 (sensors start outdated, sensor_base.py _initialize_impl).  The stamp (counters[2] + 1
+                                    as uint bits) makes a second imx_observations call within one step repeat the first one's decision
+                                    instead of advancing the sensor clock again */
     float* scan_hit_z;           /* (N,R) data.ray_hits_w[..., 2] kept for envs whose sensor is not outdated at the next step */
     const float* scan_drift_feed;/* optional (N,3): drift values taken at a sensor reset instead of the in-kernel draw (parity runs) */
 } imx_buffers_t;
@@ -244,9 +246,13 @@ int imx_action_process(const imx_plan_t* plan, int64_t num_envs, const float* ac
 /* Post-physics, pre-reset half of ManagerBasedRLEnv.step (envs/manager_based_rl_env.py:200-230):
  * episode_length_buf += 1; TerminationManager.compute; RewardManager.compute(dt); reset_env_ids = nonzero(reset_buf);
  * the manager-side part of _reset_idx (:347-392): Episode_* log reductions, episode sums / actions / episode length
- * zeroed for reset envs. */
+ * zeroed for reset envs.
+ * flags bit 0: leave the end of the step -- reset_env_ids, the reset count (counters[0]) and the Episode_* entries of log_out,
+ * which need every env group's partial results -- to the imx_observations call that follows on the same stream (its
+ * enable_corruption bit 4): a kernel boundary then orders them instead of a fence + ticket inside this launch.  Masks, rewards,
+ * episodic sums and the reset of manager state are complete either way. */
 int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state,
-                             const imx_buffers_t* buf, imx_stream_t stream);
+                             const imx_buffers_t* buf, int flags, imx_stream_t stream);
 
 /* ObservationManager.compute (managers/observation_manager.py:238-335) fused with RayCaster._update_buffers_impl
  * (sensors/ray_caster/ray_caster.py:220-260) + raycast_mesh (utils/warp/ops.py:24-127).
@@ -256,6 +262,7 @@ int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx
  * utils/buffers/circular_buffer.py:107-135) in the obs row itself: envs flagged in buf->reset_buf -- or every env when bit 1
  * of enable_corruption is set (env.reset()) -- take the new value in every slot, the others slide by one.  * enable_corruption bit 2 (value 4): the per-env frame table (root-frame vectors, scanner yaw) is current -- imx_terminations_rewards was
  * called with root_pos_w on the SAME state tensors since they last changed and wrote it -- so the k_frame launch is skipped.
+ * enable_corruption bit 4 (value 16): finish the step tail a preceding imx_terminations_rewards (flags bit 0) deferred.
  * enable_corruption bit 3 (value 8): with a stateful height scanner, keep the hit heights of EVERY env in scan_hit_z, not only of
  * those whose fp32 timestamps say they will skip the next update (a caller that is about to overwrite the timestamps in scan_state). */
 int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
@@ -272,8 +279,8 @@ int imx_root_frame(int64_t num_envs, const float* quat_wxyz_d, const float* lin_
 int imx_mesh_create(const float* vertices_h, int64_t num_vertices, const uint32_t* triangles_h, int64_t num_triangles,
                     float cell_size, imx_mesh_t** out);
 void imx_mesh_destroy(imx_mesh_t* mesh);
-/* info[0..7] = nx, ny, num_triangles, general triangle records, max refs per cell, lattice cells, general cells,
- * cell size (float bits) */
+/* info[0..7] = nx, ny, num_triangles, general triangle records, max refs per cell (low 32 bits) | FLAT cells (high 32 bits),
+ * lattice cells, general cells (FLAT ones included), cell size (float bits) */
 int imx_mesh_info(const imx_mesh_t* mesh, int64_t* info8);
 
 /* raycast_mesh (utils/warp/ops.py:24-127): closest hit per ray, misses = +inf / face -1. */
@@ -355,11 +362,13 @@ int imx_policy_act(int64_t N, int64_t A, int64_t D, const float* mu_d, const flo
                    float* actions_env_d, imx_stream_t stream);
 
 /* RslRlVecEnvWrapper.step dones (isaaclab_rl/rsl_rl/vecenv_wrapper.py:178) + rsl_rl PPO.process_env_step time-out
- * bootstrap (rewards += gamma * values * time_outs) + the runner's episode statistics, into slot t of the storage. */
+ * bootstrap (rewards += gamma * values * time_outs) + the runner's episode statistics, into slot t of the storage.
+ * log_accum_d (optional, num_log floats) += log_in_d: the per-step extras["log"] entries (imx_buffers.log_out,
+ * envs/manager_based_rl_env.py:365-389) summed on the device for the runner's per-iteration ep_infos mean. */
 int imx_rollout_post(int64_t N, const float* reward_d, const uint8_t* terminated_d, const uint8_t* truncated_d,
                      const float* value_t_d, float gamma, int bootstrap_time_outs, float* rewards_out_d,
                      uint8_t* dones_out_d, int64_t* dones_long_d, float* cur_reward_sum_d, float* cur_ep_len_d,
-                     float* ep_stats3_d, imx_stream_t stream);
+                     float* ep_stats3_d, const float* log_in_d, float* log_accum_d, int num_log, imx_stream_t stream);
 
 /* ---- input producers -------------------------------------------------------------------- */
 

@@ -57,7 +57,7 @@ _SIGNATURES = {
     "imx_plan_scratch_bytes": (c_size_t, [c_void_p, c_int64]),
     "imx_plan_obs_dim": (c_int, [c_void_p]),
     "imx_action_process": (c_int, [c_void_p, c_int64, c_void_p, c_float, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
-    "imx_terminations_rewards": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
+    "imx_terminations_rewards": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_int, c_void_p]),
     "imx_observations": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p, c_void_p, c_uint64,
                                  c_int, c_void_p, c_void_p]),
     "imx_root_frame": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
@@ -88,7 +88,7 @@ _SIGNATURES = {
     "imx_policy_act": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p] + [c_void_p] * 7
                        + [c_void_p]),
     "imx_rollout_post": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "imx_contact_sensor_update": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_float, c_float, c_float, c_int] + [c_void_p] * 9
                                   + [c_void_p]),
     "imx_velocity_command": (c_int, [c_int64, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

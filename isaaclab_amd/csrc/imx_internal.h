@@ -87,6 +87,9 @@ PlanView imx_plan_view(const imx_plan* p);
 //                                a box face covering hundreds of cells stays hot in L2):
 //                                ax ay az bx | by bz cx cy | cz face(int) ztop 0
 //                     3 GENERAL_IND  the same through gtab[desc>>2] = {first record, count} (first >= 2^24 or count > 63)
+//                     FLAT (a GENERAL / GENERAL_IND cell with bit 31 of id0 set): the highest surface over the cell's interior is
+//                                horizontal at height w (which then replaces zrest): a downward vertical ray that is not within tau
+//                                of a cell boundary hits z = w -- the descriptor answers it, no record is loaded (mesh.hip).
 #define IMX_CELL_EMPTY 0
 #define IMX_CELL_LATTICE 1
 #define IMX_CELL_GENERAL 2
@@ -111,7 +114,7 @@ struct imx_mesh {
     int32_t* d_refs = nullptr;
     int64_t num_refs = 0;  // general cell references
     int32_t max_refs = 0;
-    int64_t n_lattice = 0, n_general = 0;
+    int64_t n_lattice = 0, n_general = 0, n_flat = 0;
 };
 // linear index of cell (ix, iy) in the 8x8-tiled layout
 static __host__ __device__ __forceinline__ int imx_cell_index(int ix, int iy, int ntx) {

@@ -108,7 +108,7 @@ IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, floa
         const int32_t f0 = (int32_t)((uint32_t)d >> 2);
         test_tri(r, va, vb, vc, f0, best, face);      // (a, b, c)
         test_tri(r, va, vd, vb, f0 + 1, best, face);  // (a, d, b)
-    } else if (kind != IMX_CELL_EMPTY) {
+    } else if (kind != IMX_CELL_EMPTY) {  // (the FLAT mark of a descriptor lives in its id0 word, which this path does not read)
         int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
         if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
         for (int k = g.x; k < g.x + g.y; k += 2) {
@@ -149,10 +149,17 @@ IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_,
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     const float det = U + V + W;
     if (det == 0.0f) return;
-    const float Az = Sz * (az_ - oz), Bz = Sz * (bz_ - oz), Cz = Sz * (cz_ - oz);
-    const float T = U * Az + V * Bz + W * Cz;
-    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return;
-    const float t = T * (1.0f / det);
+    float t;
+    if (az_ == bz_ && bz_ == cz_) {
+        // a horizontal face (box tops, stair treads, platforms): the hit parameter is the height difference itself; the barycentric
+        // sum T / det of three equal terms would only add rounding (and a division) to it
+        t = Sz * (az_ - oz);
+    } else {
+        const float Az = Sz * (az_ - oz), Bz = Sz * (bz_ - oz), Cz = Sz * (cz_ - oz);
+        const float T = U * Az + V * Bz + W * Cz;
+        if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return;
+        t = T * (1.0f / det);
+    }
     if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
         best = t;
         face = f;
@@ -180,12 +187,21 @@ IMX_DEV void vertical_cell_tail(const MeshView& m, int32_t d, float ox, float oy
 }
 
 IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
-                           float& best, int32_t& face) {
+                           bool interior, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int4 d4 = m.cell_desc[c];
+    int4 d4 = m.cell_desc[c];
     const int32_t d = d4.x;
     const int kind = d & 3;
+    if (d4.y < 0) {  // FLAT cell (see imx_internal.h): the descriptor answers an interior downward ray
+        d4.y &= 0x7FFFFFFF;
+        if (interior && flip) {
+            const float t = Sz * (__int_as_float(d4.w) - oz);
+            if (t >= 0.0f && (t < best || (face < 0 && t <= best))) { best = t; face = d4.y; }
+            return;
+        }
+        d4.w = __float_as_int(__builtin_huge_valf());  // w held the height, not zrest: no early exit on the first pair
+    }
     if (kind == IMX_CELL_LATTICE) {  // height-field quad: descriptor -> 4 shared corners of the tile's vertex pool
         const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
         const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
@@ -220,11 +236,11 @@ IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, 
     int nbx, nby;
     const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
     const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);
-    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, best, face);
+    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, (nbx | nby) == 0, best, face);
     if (nbx | nby) {  // within tau of a cell boundary (rare): the neighbouring cells as well
-        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, best, face);
-        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, best, face);
-        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, best, face);
+        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, false, best, face);
+        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, false, best, face);
+        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, false, best, face);
     }
     if (face < 0) return false;
     t_hit = best;

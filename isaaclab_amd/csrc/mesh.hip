@@ -2,12 +2,50 @@
 // wp.Mesh's BVH build (reference isaaclab/utils/warp/ops.py:130-145, called once at RayCaster init,
 // sensors/ray_caster/ray_caster.py:182-189).  Membership rule and cell encodings: see imx_raycast.h.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
 
 #include "imx_internal.h"
+
+// area of triangle (grid units) clipped to the axis-aligned square [x0,x1] x [y0,y1] (Sutherland-Hodgman + shoelace)
+static double clipped_area(const double tri[3][2], double x0, double y0, double x1, double y1) {
+    double px[16], py[16], qx[16], qy[16];
+    int n = 3;
+    for (int i = 0; i < 3; ++i) { px[i] = tri[i][0]; py[i] = tri[i][1]; }
+    for (int side = 0; side < 4 && n > 0; ++side) {
+        int m = 0;
+        auto inside = [&](double x, double y) { return side == 0 ? x >= x0 : side == 1 ? x <= x1 : side == 2 ? y >= y0 : y <= y1; };
+        for (int i = 0; i < n; ++i) {
+            const double ax = px[i], ay = py[i], bx = px[(i + 1) % n], by = py[(i + 1) % n];
+            const bool ia = inside(ax, ay), ib = inside(bx, by);
+            if (ia) { qx[m] = ax; qy[m] = ay; ++m; }
+            if (ia != ib) {
+                double t;
+                if (side < 2) { const double xb = side == 0 ? x0 : x1; t = (xb - ax) / (bx - ax); qx[m] = xb; qy[m] = ay + t * (by - ay); }
+                else { const double yb = side == 2 ? y0 : y1; t = (yb - ay) / (by - ay); qy[m] = yb; qx[m] = ax + t * (bx - ax); }
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+    }
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += px[i] * py[(i + 1) % n] - px[(i + 1) % n] * py[i];
+    return 0.5 * std::fabs(a);
+}
+
+static bool point_in_tri(const double tri[3][2], double x, double y, double eps) {
+    double s[3];
+    for (int e = 0; e < 3; ++e) {
+        const double* a = tri[e];
+        const double* b = tri[(e + 1) % 3];
+        s[e] = (b[0] - a[0]) * (y - a[1]) - (b[1] - a[1]) * (x - a[0]);
+    }
+    return (s[0] >= -eps && s[1] >= -eps && s[2] >= -eps) || (s[0] <= eps && s[1] <= eps && s[2] <= eps);
+}
 
 static inline void cell_range(float lo, float hi, float origin, float inv_cell, int n, int& a, int& b) {
     // same fp32 expression as the device (imx_raycast.h: cell_of)
@@ -142,7 +180,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         // downward early exit must not wait for their tops.  The generic DDA path tests the whole list in any order.
         if ((rec[0] == rec[3] && rec[3] == rec[6]) || (rec[1] == rec[4] && rec[4] == rec[7])) ztop[f] = -INFINITY;
     }
-    int64_t n_lattice = 0, n_general = 0;
+    int64_t n_lattice = 0, n_general = 0, n_flat = 0;
     auto single_cell = [&](int32_t f) {
         return ra[(size_t)f * 4] == ra[(size_t)f * 4 + 1] && ra[(size_t)f * 4 + 2] == ra[(size_t)f * 4 + 3];
     };
@@ -215,6 +253,51 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                     for (int k = 2; k < n; ++k) zr = std::max(zr, order[k].first);
                     memcpy(&desc[(size_t)c * 4 + 3], &zr, 4);
                 }
+                // FLAT: the highest surface over the cell is horizontal -- faces whose three vertices share the height h = the list's
+                // highest top -- and those faces cover the whole interior of the cell (what a ray that is not within tau of a cell
+                // boundary can reach).  Everything else in the list lies at or below h, so a DOWNWARD vertical ray through the
+                // interior hits z = h whatever triangle it is: the descriptor alone answers it (bit 31 of id0 set, w = h) -- no
+                // record loads, no edge functions, no division.  Box tops, stair treads, platforms, the border ring.
+                {
+                    const float h = order[0].first;
+                    double area = 0.0;
+                    std::vector<std::array<std::array<double, 2>, 3>> flat;
+                    if (std::isfinite(h))
+                        for (int k = 0; k < n; ++k) {
+                            const float* rec = &recs[(size_t)r[k] * 12];
+                            if (rec[2] == h && rec[5] == h && rec[8] == h) {
+                                std::array<std::array<double, 2>, 3> t;
+                                for (int cc = 0; cc < 3; ++cc) {
+                                    t[cc][0] = ((double)rec[cc * 3] - (double)xmin) * (double)inv_cell;
+                                    t[cc][1] = ((double)rec[cc * 3 + 1] - (double)ymin) * (double)inv_cell;
+                                }
+                                flat.push_back(t);
+                            }
+                        }
+                    const double m = 0.5 * (double)IMX_GRID_TAU;  // the square interior rays live in, grown a little
+                    const double x0 = ix + m, x1 = ix + 1 - m, y0 = iy + m, y1 = iy + 1 - m;
+                    bool covered = !flat.empty();
+                    for (const auto& t : flat) {
+                        const double tri[3][2] = {{t[0][0], t[0][1]}, {t[1][0], t[1][1]}, {t[2][0], t[2][1]}};
+                        area += clipped_area(tri, x0, y0, x1, y1);
+                    }
+                    covered = covered && area >= (x1 - x0) * (y1 - y0) * (1.0 - 1e-9);
+                    for (int sy = 0; sy < 5 && covered; ++sy)  // overlapping coplanar faces could fake the area: sample as well
+                        for (int sx = 0; sx < 5 && covered; ++sx) {
+                            const double qx = x0 + (x1 - x0) * sx / 4.0, qy = y0 + (y1 - y0) * sy / 4.0;
+                            bool in = false;
+                            for (const auto& t : flat) {
+                                const double tri[3][2] = {{t[0][0], t[0][1]}, {t[1][0], t[1][1]}, {t[2][0], t[2][1]}};
+                                if (point_in_tri(tri, qx, qy, 1e-9)) { in = true; break; }
+                            }
+                            covered = in;
+                        }
+                    if (covered) {
+                        desc[(size_t)c * 4 + 1] |= (int32_t)0x80000000u;
+                        memcpy(&desc[(size_t)c * 4 + 3], &h, 4);  // replaces zrest: the general path of such a cell (rays on a cell
+                        ++n_flat;                                  // boundary, slanted rays) then simply never exits early on the first pair
+                    }
+                }
                 if (first < (1u << 24) && npad < 64) {  // first ref and count inline: no second table look-up
                     desc[(size_t)c * 4] = (int32_t)(((uint32_t)first << 8) | ((uint32_t)npad << 2) | IMX_CELL_GENERAL);
                 } else {
@@ -275,6 +358,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     m->max_refs = max_refs;
     m->n_lattice = n_lattice;
     m->n_general = n_general;
+    m->n_flat = n_flat;
     *out = m.release();
     return 0;
 }
@@ -292,7 +376,8 @@ extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
 extern "C" int imx_mesh_info(const imx_mesh_t* m, int64_t* info8) {
     IMX_REQUIRE(m && info8, "imx_mesh_info: null argument");
     info8[0] = m->v.nx; info8[1] = m->v.ny; info8[2] = m->v.F; info8[3] = m->num_refs; info8[4] = m->max_refs;
-    info8[5] = m->n_lattice; info8[6] = m->n_general;
+    info8[5] = m->n_lattice; info8[6] = m->n_general;  // info8[6] includes the FLAT cells; their count rides in the upper half of info8[4]
+    info8[4] = (int64_t)m->max_refs | (m->n_flat << 32);
     int32_t b;
     memcpy(&b, &m->v.cell, 4); info8[7] = b;
     return 0;

@@ -588,8 +588,13 @@ __global__ void __launch_bounds__(256)
 k_rollout_post(int64_t N, const float* __restrict__ rew, const uint8_t* __restrict__ terminated,
                const uint8_t* __restrict__ truncated, const float* __restrict__ value_t, float gamma, int bootstrap,
                float* __restrict__ rew_out, uint8_t* __restrict__ dones_out, int64_t* __restrict__ dones_long,
-               float* __restrict__ cur_rew, float* __restrict__ cur_len, float* __restrict__ ep_stats) {
+               float* __restrict__ cur_rew, float* __restrict__ cur_len, float* __restrict__ ep_stats,
+               const float* __restrict__ log_in, float* __restrict__ log_accum, int nlog) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the runner's ep_infos (upstream on_policy_runner.py: infos["log"] appended every step, averaged per iteration): the env's
+    // Episode_* entries of this step are added to a running sum by ONE workgroup (fixed order: deterministic)
+    if (log_accum && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nlog; i += blockDim.x) log_accum[i] += log_in[i];
     float s_r = 0.0f, s_l = 0.0f, s_c = 0.0f;
     if (e < N) {
         const bool to = truncated[e] != 0, done = to || terminated[e] != 0;
@@ -618,13 +623,14 @@ k_rollout_post(int64_t N, const float* __restrict__ rew, const uint8_t* __restri
 extern "C" int imx_rollout_post(int64_t N, const float* reward_d, const uint8_t* terminated_d, const uint8_t* truncated_d,
                                 const float* value_t_d, float gamma, int bootstrap_time_outs, float* rewards_out_d,
                                 uint8_t* dones_out_d, int64_t* dones_long_d, float* cur_reward_sum_d, float* cur_ep_len_d,
-                                float* ep_stats3_d, imx_stream_t stream) {
+                                float* ep_stats3_d, const float* log_in_d, float* log_accum_d, int num_log, imx_stream_t stream) {
     IMX_REQUIRE(N > 0 && reward_d && terminated_d && truncated_d && value_t_d && rewards_out_d && dones_out_d,
                 "imx_rollout_post: bad arguments");
+    IMX_REQUIRE(!log_accum_d || (log_in_d && num_log > 0), "imx_rollout_post: log accumulation needs log_in_d and num_log > 0");
     IMX_REQUIRE((cur_reward_sum_d == nullptr) == (cur_ep_len_d == nullptr), "imx_rollout_post: episode buffers come together");
     hipLaunchKernelGGL(k_rollout_post, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, reward_d,
                        terminated_d, truncated_d, value_t_d, gamma, bootstrap_time_outs, rewards_out_d, dones_out_d,
-                       dones_long_d, cur_reward_sum_d, cur_ep_len_d, ep_stats3_d);
+                       dones_long_d, cur_reward_sum_d, cur_ep_len_d, ep_stats3_d, log_in_d, log_accum_d, num_log);
     IMX_HIP(hipGetLastError());
     return 0;
 }

@@ -20,65 +20,90 @@ IMX_DEV int wave_sum_i(int v) {
     return v;
 }
 
-// Sequential-order sum of f(ids[i]), i = 0..n-1, with the loads of 8 terms issued before the first add: the adds
-// keep torch.sum's left-to-right order for these short rows while the memory latency is paid once per 8 elements.
+// Sequential-order sum of f(ids[i]), i = 0..n-1 (torch.sum's left-to-right order for these short rows).  Full trips of 8 issue
+// their loads before the first add; the remainder runs one by one -- no padded duplicates: for the force-history terms one
+// element costs ~40 instructions and the slowest term is the kernel's critical path.
 template <class F>
 IMX_DEV float sum_ids(const int32_t* __restrict__ ids, int n, F f) {
     float acc = 0.0f;
-    for (int i = 0; i < n; i += 8) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
         float x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = f(ids[min(i + u, n - 1)]);
+        for (int u = 0; u < 8; ++u) x[u] = f(ids[i + u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i + u < n) acc += x[u];
+        for (int u = 0; u < 8; ++u) acc += x[u];
     }
+    for (; i + 4 <= n; i += 4) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = f(ids[i + u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += x[u];
+    }
+    for (; i < n; ++i) acc += f(ids[i]);
     return acc;
 }
 template <class F>
 IMX_DEV float sum_range(int n, F f) {
     float acc = 0.0f;
-    for (int i = 0; i < n; i += 8) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
         float x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = f(min(i + u, n - 1));
+        for (int u = 0; u < 8; ++u) x[u] = f(i + u);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i + u < n) acc += x[u];
+        for (int u = 0; u < 8; ++u) acc += x[u];
     }
+    for (; i + 4 <= n; i += 4) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = f(i + u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += x[u];
+    }
+    for (; i < n; ++i) acc += f(i);
     return acc;
 }
 template <class F>
 IMX_DEV bool any_ids(const int32_t* __restrict__ ids, int n, F f) {
     bool acc = false;
-    for (int i = 0; i < n; i += 8) {
-        bool x[8];
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        bool x[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = f(ids[min(i + u, n - 1)]);
+        for (int u = 0; u < 4; ++u) x[u] = f(ids[i + u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = acc || x[u];  // duplicates of the last id are harmless for 'any'
+        for (int u = 0; u < 4; ++u) acc = acc || x[u];
     }
+    for (; i < n; ++i) acc = f(ids[i]) || acc;
     return acc;
 }
 
-// max over history of the force norm on body b (rewards.py:266, terminations.py:157); 4 history slots per trip
+// max over history of the force norm on body b (rewards.py:266, terminations.py:157): max_h sqrt(s_h) with s_h = (x^2 + y^2) + z^2.
+// sqrtf is correctly rounded and monotone, so max_h sqrt(s_h) == sqrt(max_h s_h) bit for bit: ONE square root per body.
 IMX_DEV float max_hist_force(const float* __restrict__ F, int64_t e, int H, int B, int b) {
-    float m = -__builtin_huge_valf();
-    for (int h0 = 0; h0 < H; h0 += 4) {
-        float nrm[4];
+    const float* f = F + ((size_t)e * H * B + b) * 3;
+    float m = 0.0f;  // squared norms are >= 0
+    int h = 0;
+    for (; h + 3 <= H; h += 3) {  // the usual history_length = 3 in one trip
+        float v[9];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int h = min(h0 + u, H - 1);
-            const float* f = F + (((size_t)e * H + h) * B + b) * 3;
-            nrm[u] = norm3(f[0], f[1], f[2]);
+        for (int u = 0; u < 3; ++u) {
+            const float* g = f + (size_t)(h + u) * B * 3;
+            v[3 * u] = g[0]; v[3 * u + 1] = g[1]; v[3 * u + 2] = g[2];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) m = fmaxf(m, nrm[u]);
+        for (int u = 0; u < 3; ++u) m = fmaxf(m, (v[3 * u] * v[3 * u] + v[3 * u + 1] * v[3 * u + 1]) + v[3 * u + 2] * v[3 * u + 2]);
     }
-    return m;
+    for (; h < H; ++h) {
+        const float* g = f + (size_t)h * B * 3;
+        m = fmaxf(m, (g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+    }
+    return sqrtf(m);
 }
 
-// scratch layout for k_term_rew (4-byte words, nw = number of env groups, sized for the smaller group: ceil(N/32))
+// scratch layout for k_term_rew (4-byte words, nw = number of env groups; sized for the smallest group: ceil(N/16) groups)
 //   [0, nw*KA)               float  per-group partial sums of episode_sums over reset envs
 //   [.., + nw*NT)            int    per-group counts of term_dones over reset envs
 //   [.., + nw)               int    per-group reset counts
@@ -89,12 +114,17 @@ struct StepScratch {
     int* wave_cnt;
     int* ids_local;
 };
+// envs per workgroup of k_term_rew: every lane of a wave reads its own row of the (N, dof|bodies) state tensors, so a load instruction
+// touches one cache line per live lane and the CU's L1 serves one line per clock -- at 4096 envs 64-env groups keep 64 of the 256
+// CUs busy walking 64 lines per load (phase 1 measured 9.4 us), 16-env groups spread the same lines over all 256 CUs.  Full waves
+// win once there are enough groups to fill the chip anyway.
+static inline int step_group_size(int64_t N) { return N <= 8192 ? 16 : (N <= 16384 ? 32 : 64); }
 static inline size_t step_scratch_words(int64_t N, int KA, int NT) {
-    const size_t nw = (size_t)((N + 31) / 32);
+    const size_t nw = (size_t)((N + 15) / 16);
     return nw * KA + nw * NT + nw + nw * 64;
 }
 static inline StepScratch carve(void* base, int64_t N, int KA, int NT) {
-    const size_t nw = (size_t)((N + 31) / 32);
+    const size_t nw = (size_t)((N + 15) / 16);
     StepScratch s;
     s.log_part = (float*)base;
     s.term_part = (int*)(s.log_part + nw * KA);
@@ -149,302 +179,31 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
     }
 }
 
-// ------------------------------------------------------------------------------------------------- terminations + rewards
-// Block = 64 consecutive envs x IMX_TR_WAVES waves.  Lane l of every wave owns env 64*blockIdx + l.  Every wave evaluates the
-// (cheap) termination terms, so each knows its envs' reset flags; the reward terms are dealt round-robin to the four
-// waves (4x the loads in flight per env), each wave finishing its own terms completely (value, episodic sum,
-// step_reward, reset-log partial).  The per-term values meet in LDS and wave 0 adds them IN TERM ORDER, so the
-// reward is bit-identical to a single-wave sequential evaluation.
-// G = envs per workgroup: 64 (every lane an env) or 32 (upper half-waves idle): at 4096 envs 64-env groups are only 64
-// workgroups on 256 CUs and the kernel is one latency chain long, so twice as many half-filled groups finish sooner; from
-// 16384 envs on the full groups win.
-#define IMX_TR_WAVES 8
-template <int G>
-__global__ void __launch_bounds__(64 * IMX_TR_WAVES)
-k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame) {
-    extern __shared__ float s_val[];  // [nrew][64]
+#ifdef IMX_TRACE  // tools/trace_kobs.py only: per-wave start / end stamps (100 MHz wall clock) and placement; never in libimx.so
+__device__ uint64_t* g_trace = nullptr;
+extern "C" int imx_debug_trace(uint64_t* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)); }
+#endif
+#ifdef IMX_TRACE
+#define IMX_STAMP(k) do { if (g_trace && lane == 0) g_trace[((size_t)blockIdx.x * 16 + wv) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define IMX_STAMP(k) do { } while (0)
+#endif
+#define IMX_TR_MAX_WAVES 16
+// The end of the step: ordered concatenation of the per-group reset-id lists (reset_env_ids = reset_buf.nonzero(),
+// manager_based_rl_env.py:215), the reset count, and the Episode_* log reductions of RewardManager.reset / TerminationManager.reset
+// (reward_manager.py:115-121, termination_manager.py:142-144) in a fixed order (deterministic, no float atomics).  ONE workgroup
+// runs it after every group's partials are visible: the last-arriving workgroup of k_term_rew, or -- inside env.step() -- an extra
+// workgroup of the observation kernel that follows (a kernel boundary instead of a fence + ticket: 4.9 us off the step kernel).
+IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, const StepScratch& sc, int G) {
+    __shared__ int s_scan[IMX_TR_MAX_WAVES];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t grp = blockIdx.x;
-    const int64_t e = grp * G + lane;
-    const bool live = lane < G && e < N;
-    const int64_t ec = live ? e : N - 1;  // clamp: dead lanes compute on a valid env, never store
-    const int J = P.J, Bn = P.B, H = P.H, A = P.A;
-    const int32_t* __restrict__ W = P.w;
-
-    // -- root frame (ArticulationData.root_lin_vel_b / root_ang_vel_b / projected_gravity_b)
-    const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[ec];
-    const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
-    const float lwx = S.root_lin_vel_w[ec * 3], lwy = S.root_lin_vel_w[ec * 3 + 1], lwz = S.root_lin_vel_w[ec * 3 + 2];
-    const float awx = S.root_ang_vel_w[ec * 3], awy = S.root_ang_vel_w[ec * 3 + 1], awz = S.root_ang_vel_w[ec * 3 + 2];
-    const int64_t ep = Bf.episode_length_buf[ec] + 1;  // manager_based_rl_env.py:200
-    const float cmdx = P.CMD > 0 ? S.command[ec * P.CMD + 0] : 0.0f;
-    const float cmdy = P.CMD > 1 ? S.command[ec * P.CMD + 1] : 0.0f;
-    const float cmdz = P.CMD > 2 ? S.command[ec * P.CMD + 2] : 0.0f;
-    float lbx, lby, lbz, abx, aby, abz, pgx, pgy, pgz;
-    quat_rotate_inverse(qw, qx, qy, qz, lwx, lwy, lwz, lbx, lby, lbz);
-    quat_rotate_inverse(qw, qx, qy, qz, awx, awy, awz, abx, aby, abz);
-    quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, pgx, pgy, pgz);
-
-    // -- the env's frame table for the observation kernel of the same step (what k_frame writes: same functions, same inputs, so
-    //    bit-identical); the last wave has the fewest reward terms to evaluate
-    if (frame && wv == IMX_TR_WAVES - 1 && live) {
-        float4 o[5];
-        o[0] = make_float4(lbx, lby, lbz, abx);
-        o[1] = make_float4(aby, abz, pgx, pgy);
-        o[2] = make_float4(pgz, S.root_pos_w[e * 3], S.root_pos_w[e * 3 + 1], S.root_pos_w[e * 3 + 2]);
-        o[3] = q4;
-        o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, o[4].x, o[4].y);
-        float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) dst[k] = o[k];
-    }
-
-    // -- TerminationManager.compute (termination_manager.py:151-174)
-    uint32_t term_bits = 0;
-    bool terminated = false, truncated = false;
-    for (int k = 0; k < P.nterm; ++k) {
-        const int32_t* r = W + P.term_off + k * IMX_REC_WORDS;
-        const int op = r[IMX_R_OP];
-        const int32_t* ids = W + r[IMX_R_IDS_OFF];
-        const int n = r[IMX_R_NIDS];
-        const float p0 = f_of(r[IMX_R_P0]), p1 = f_of(r[IMX_R_P1]);
-        bool v = false;
-        switch (op) {
-            case IMX_T_TIME_OUT: v = ep >= (int64_t)P.max_ep_len; break;
-            case IMX_T_ILLEGAL_CONTACT:
-                v = any_ids(ids, n, [&](int b) { return max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0; });
-                break;
-            case IMX_T_JOINT_POS_MANUAL_LIMIT:
-                v = any_ids(ids, n, [&](int j) { const float q = S.joint_pos[ec * J + j]; return (q > p1) || (q < p0); });
-                break;
-            case IMX_T_BAD_ORIENTATION: v = fabsf(acosf(-pgz)) > p0; break;
-            case IMX_T_ROOT_HEIGHT_BELOW_MIN: v = S.root_pos_w[ec * 3 + 2] < p0; break;
-            case IMX_T_JOINT_VEL_LIMIT:
-                v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > S.soft_joint_vel_limits[ec * J + j]; });
-                break;
-            case IMX_T_JOINT_VEL_MANUAL_LIMIT:
-                v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > p0; });
-                break;
-            case IMX_T_JOINT_EFFORT_LIMIT:  // torch.isclose(computed, applied): |a-b| <= atol + rtol*|b|
-                v = any_ids(ids, n, [&](int j) {
-                    const float a = S.computed_torque[ec * J + j], b = S.applied_torque[ec * J + j];
-                    return fabsf(a - b) <= 1.0e-8f + 1.0e-5f * fabsf(b);
-                });
-                break;
-            case IMX_T_TERRAIN_OUT_OF_BOUNDS:
-                v = (fabsf(S.root_pos_w[ec * 3]) > p0) || (fabsf(S.root_pos_w[ec * 3 + 1]) > p1);
-                break;
-            case IMX_T_EXTERNAL: v = S.ext_term[ec * (int64_t)W[IMX_H_NEXT_TERM] + r[IMX_R_AUX0]] != 0; break;
-            case IMX_T_COMMAND_RESAMPLE:  // (time_left <= step_dt) & (command_counter == num_resamples)
-                v = (S.command_time_left[ec] <= p0) && (S.command_counter[ec] == (int64_t)n);
-                break;
-            default: break;
-        }
-        if (r[IMX_R_WEIGHT]) truncated = truncated || v; else terminated = terminated || v;
-        term_bits |= v ? (1u << k) : 0u;
-        if (live && wv == 0) Bf.term_dones[(size_t)k * N + e] = v ? 1 : 0;
-    }
-    const bool reset = live && (terminated || truncated);
-
-    // -- RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; sums += value; step_reward = value/dt
-    const float dt = P.step_dt;
-    const bool moving = sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f;  // torch.norm(cmd[:, :2]) > 0.1
-    for (int k = wv; k < P.nrew; k += IMX_TR_WAVES) {
-        const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
-        const int idx = r[IMX_R_OUT];
-        const float es0 = live ? Bf.episode_sums[(size_t)idx * N + e] : 0.0f;  // issued early: independent of the term
-        const float weight = f_of(r[IMX_R_WEIGHT]);
-        if (weight == 0.0f) {
-            // skipped by compute (reward_manager.py:145: no value, step_reward keeps what it held), but the slot still takes part in
-            // the reset / log pass (reward_manager.py:100-126)
-            s_val[k * 64 + lane] = 0.0f;
-            const float part = wave_sum(reset ? es0 : 0.0f);
-            if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
-            if (reset) Bf.episode_sums[(size_t)idx * N + e] = 0.0f;
-            continue;
-        }
-        const int op = r[IMX_R_OP];
-        const int32_t* ids = W + r[IMX_R_IDS_OFF];
-        const int n = r[IMX_R_NIDS];
-        const float p0 = f_of(r[IMX_R_P0]);
-        float f = 0.0f;
-        switch (op) {
-            case IMX_W_IS_ALIVE: f = terminated ? 0.0f : 1.0f; break;
-            case IMX_W_IS_TERMINATED: f = terminated ? 1.0f : 0.0f; break;
-            case IMX_W_IS_TERMINATED_TERM: {
-                float s = 0.0f;
-                for (int i = 0; i < n; ++i) s += ((term_bits >> ids[i]) & 1u) ? 1.0f : 0.0f;
-                f = s * (truncated ? 0.0f : 1.0f);
-            } break;
-            case IMX_W_LIN_VEL_Z_L2: f = lbz * lbz; break;
-            case IMX_W_ANG_VEL_XY_L2: f = abx * abx + aby * aby; break;
-            case IMX_W_FLAT_ORIENTATION_L2: f = pgx * pgx + pgy * pgy; break;
-            case IMX_W_BASE_HEIGHT_L2: { const float d = S.root_pos_w[ec * 3 + 2] - p0; f = d * d; } break;
-            case IMX_W_JOINT_TORQUES_L2:
-                f = sum_ids(ids, n, [&](int j) { const float x = S.applied_torque[ec * J + j]; return x * x; });
-                break;
-            case IMX_W_JOINT_VEL_L1: f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]); }); break;
-            case IMX_W_JOINT_VEL_L2:
-                f = sum_ids(ids, n, [&](int j) { const float x = S.joint_vel[ec * J + j]; return x * x; });
-                break;
-            case IMX_W_JOINT_ACC_L2:
-                f = sum_ids(ids, n, [&](int j) { const float x = S.joint_acc[ec * J + j]; return x * x; });
-                break;
-            case IMX_W_JOINT_DEVIATION_L1:
-                f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_pos[ec * J + j] - S.default_joint_pos[ec * J + j]); });
-                break;
-            case IMX_W_JOINT_POS_LIMITS:
-                f = sum_ids(ids, n, [&](int j) {
-                    const float q = S.joint_pos[ec * J + j];
-                    const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[ec * J + j];
-                    float o = -fminf(q - lim.x, 0.0f);
-                    o += fmaxf(q - lim.y, 0.0f);
-                    return o;
-                });
-                break;
-            case IMX_W_JOINT_VEL_LIMITS:
-                f = sum_ids(ids, n, [&](int j) {
-                    const float o = fabsf(S.joint_vel[ec * J + j]) - S.soft_joint_vel_limits[ec * J + j] * p0;
-                    return fminf(fmaxf(o, 0.0f), 1.0f);
-                });
-                break;
-            case IMX_W_APPLIED_TORQUE_LIMITS:
-                f = sum_ids(ids, n, [&](int j) { return fabsf(S.applied_torque[ec * J + j] - S.computed_torque[ec * J + j]); });
-                break;
-            case IMX_W_ACTION_RATE_L2:
-                f = sum_range(A, [&](int i) { const float d = Bf.action[ec * A + i] - Bf.prev_action[ec * A + i]; return d * d; });
-                break;
-            case IMX_W_ACTION_L2:
-                f = sum_range(A, [&](int i) { const float a = Bf.action[ec * A + i]; return a * a; });
-                break;
-            case IMX_W_UNDESIRED_CONTACTS:
-                f = sum_ids(ids, n, [&](int b) { return (max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0) ? 1.0f : 0.0f; });
-                break;
-            case IMX_W_CONTACT_FORCES:
-                f = sum_ids(ids, n, [&](int b) { return fmaxf(max_hist_force(S.net_forces_w_history, ec, H, Bn, b) - p0, 0.0f); });
-                break;
-            case IMX_W_TRACK_LIN_VEL_XY_EXP: {
-                const float ex = cmdx - lbx, ey = cmdy - lby;
-                f = expf(-(ex * ex + ey * ey) / p0);  // p0 = std**2
-            } break;
-            case IMX_W_TRACK_ANG_VEL_Z_EXP: { const float ez = cmdz - abz; f = expf(-(ez * ez) / p0); } break;
-            case IMX_W_FEET_AIR_TIME: {
-                // first_contact = (cct > 0) * (cct < dt + abs_tol); p1 = float32(step_dt + 1e-8)
-                const float p1 = f_of(r[IMX_R_P1]);
-                f = sum_ids(ids, n, [&](int b) {
-                    const float cct = S.current_contact_time[ec * Bn + b];
-                    const float fc = (cct > 0.0f && cct < p1) ? 1.0f : 0.0f;
-                    return (S.last_air_time[ec * Bn + b] - p0) * fc;
-                });
-                f *= moving ? 1.0f : 0.0f;
-            } break;
-            case IMX_W_FEET_AIR_TIME_POSITIVE_BIPED: {
-                int n_contact = 0;
-                float mn = __builtin_huge_valf();
-                for (int i = 0; i < n; ++i) n_contact += (S.current_contact_time[ec * Bn + ids[i]] > 0.0f) ? 1 : 0;
-                for (int i = 0; i < n; ++i) {
-                    const float ct = S.current_contact_time[ec * Bn + ids[i]], at = S.current_air_time[ec * Bn + ids[i]];
-                    const float in_mode = (ct > 0.0f) ? ct : at;
-                    mn = fminf(mn, (n_contact == 1) ? in_mode : 0.0f);
-                }
-                f = fminf(mn, p0);
-                f *= moving ? 1.0f : 0.0f;
-            } break;
-            case IMX_W_FEET_SLIDE: {
-                const int32_t* ids2 = W + r[IMX_R_IDS2_OFF];
-                for (int i = 0; i < n; ++i) {
-                    const float c = (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > 1.0f) ? 1.0f : 0.0f;
-                    const float* v = S.body_lin_vel_w + ((size_t)ec * P.NB + ids2[i]) * 3;
-                    f += sqrtf(v[0] * v[0] + v[1] * v[1]) * c;
-                }
-            } break;
-            case IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {
-                float yw, yz, vx, vy, vz;
-                yaw_quat_wz(qw, qx, qy, qz, yw, yz);
-                quat_rotate_inverse(yw, 0.0f, 0.0f, yz, lwx, lwy, lwz, vx, vy, vz);
-                const float ex = cmdx - vx, ey = cmdy - vy;
-                f = expf(-(ex * ex + ey * ey) / p0);
-            } break;
-            case IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP: { const float ez = cmdz - awz; f = expf(-(ez * ez) / p0); } break;
-            case IMX_W_JOINT_POS_TARGET_L2:
-                f = sum_ids(ids, n, [&](int j) { const float d = wrap_to_pi(S.joint_pos[ec * J + j]) - p0; return d * d; });
-                break;
-            case IMX_W_EXTERNAL: f = S.ext_reward[ec * (int64_t)W[IMX_H_NEXT_REW] + r[IMX_R_AUX0]]; break;
-            case IMX_W_BODY_LIN_ACC_L2:  // sum over bodies of ||body_lin_acc_w|| (rewards.py:125-128)
-                f = sum_ids(ids, n, [&](int b) {
-                    const float* a = S.body_lin_acc_w + ((size_t)ec * P.NB + b) * 3;
-                    return norm3(a[0], a[1], a[2]);
-                });
-                break;
-            default: break;
-        }
-        const float value = f * weight * dt;
-        s_val[k * 64 + lane] = value;
-        const float es = es0 + value;
-        if (live) {
-            Bf.step_reward[(size_t)e * P.nrew_all + idx] = value / dt;
-            Bf.episode_sums[(size_t)idx * N + e] = reset ? 0.0f : es;
-        }
-        // RewardManager.reset log (reward_manager.py:115-121): mean over reset envs of the episodic sum
-        const float part = wave_sum(reset ? es : 0.0f);
-        if (lane == 0) sc.log_part[grp * P.nrew_all + idx] = part;
-    }
-    __syncthreads();
-
-    if (wv == 0) {
-        float reward = 0.0f;
-        for (int k = 0; k < P.nrew; ++k) reward += s_val[k * 64 + lane];  // term order (a skipped term holds +0: x + 0 == x bit for bit)
-        // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
-        if (live) {
-            Bf.reward_buf[e] = reward;
-            Bf.terminated[e] = terminated ? 1 : 0;
-            Bf.truncated[e] = truncated ? 1 : 0;
-            Bf.reset_buf[e] = reset ? 1 : 0;
-            Bf.episode_length_buf[e] = reset ? 0 : ep;
-            if (reset)
-                for (int i = 0; i < A; ++i) {  // ActionManager.reset (action_manager.py:306-316)
-                    Bf.action[e * A + i] = 0.0f;
-                    Bf.prev_action[e * A + i] = 0.0f;
-                }
-        }
-        // TerminationManager.reset log (termination_manager.py:142-144): count_nonzero(term_dones[reset ids])
-        for (int k = 0; k < P.nterm; ++k) {
-            const int c = wave_sum_i((reset && ((term_bits >> k) & 1u)) ? 1 : 0);
-            if (lane == 0) sc.term_part[grp * P.nterm + k] = c;
-        }
-        // ordered compaction inside the group: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
-        const unsigned long long ballot = __ballot(reset);
-        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
-        if (reset) sc.ids_local[grp * 64 + before] = lane;
-        if (lane == 0) sc.wave_cnt[grp] = __popcll(ballot);
-    }
-
-    // -- last block finishes: ordered concatenation of the per-group id lists + log reductions (deterministic order)
-    __shared__ int s_last;
-    __shared__ int s_scan[IMX_TR_WAVES];
-    // producer side (cdna_hip_programming.md G16, R1): every storing wave drains its stores, the block meets at the
-    // barrier, ONE lane releases at agent scope and takes the ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = atomicAdd(&Bf.counters[1], 1);
-        s_last = (ticket == (int)gridDim.x - 1);
-        if (s_last) {  // consumer side: one agent-scope acquire, completed before the barrier releases the readers
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;
+    const int NW = blockDim.x >> 6;
     const int nw = (int)((N + G - 1) / G);
-    const int T = blockDim.x;
+    const int TB = blockDim.x;
     const int t = threadIdx.x;
-    // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + 4 wave totals
-    const int chunk = (nw + T - 1) / T;
+    // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + per-wave totals
+    const int chunk = (nw + TB - 1) / TB;
     int local = 0;
     for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) local += __builtin_nontemporal_load(&sc.wave_cnt[w]);
     int incl = local;
@@ -456,15 +215,11 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     if (lane == 63) s_scan[wv] = incl;
     __syncthreads();
     int wave_base = 0, total = 0;
-    for (int w = 0; w < IMX_TR_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if (w < wv) wave_base += s_scan[w];
         total += s_scan[w];
     }
-    if (t == 0) {
-        Bf.counters[0] = total;  // number of reset envs
-        Bf.counters[1] = 0;      // re-arm the ticket
-        Bf.counters[2] += 1;     // step counter (keys the observation-noise stream)
-    }
+    if (t == 0) Bf.counters[0] = total;  // number of reset envs
     int off = wave_base + incl - local;
     for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
         const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
@@ -475,7 +230,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
         // one wave per log entry: lanes stride over the groups, fixed-shape shuffle tree -> deterministic
         const int nlog = P.nrew_all + P.nterm;
-        for (int k = wv; k < nlog; k += IMX_TR_WAVES) {
+        for (int k = wv; k < nlog; k += NW) {
             if (k < P.nrew_all) {
                 float s = 0.0f;
                 for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
@@ -491,6 +246,341 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         }
         if (t == 0) Bf.log_out[nlog] = (float)total;
     }
+}
+
+// ------------------------------------------------------------------------------------------------- terminations + rewards
+// Block = G consecutive envs x NW waves (NW <= 16).  Lane l of every wave owns env G*blockIdx + l ("env per lane").  The work items --
+// nterm termination terms, then nrew reward terms -- are dealt round-robin to the waves, so that the state loads of ALL terms of an
+// env are in flight together and the kernel is two memory round trips deep, not one chain per term:
+//   phase 0  root state (and the episodic sum of the wave's first reward item) -- no table needed, issued first;
+//   phase 1  each wave evaluates its items: record and id list through the scalar cache (wave-uniform, L2-resident), state loads,
+//            a termination's bit into an LDS mask, a reward's RAW function value f and the env's running episodic sum into LDS;
+//   phase 2  with every termination known (is_alive / is_terminated / the reset flag need them), each wave finishes its reward
+//            items: value = f * weight * dt, episodic sum, step_reward, reset-log partial;
+//   phase 3  wave 0 adds the values IN TERM ORDER (bit-identical to the reference's sequential `+=`), writes the env outputs and
+//            the ordered reset ids of the group; the other waves store term_dones and the termination-log counts.
+// What the per-wave timeline (tools/trace_step.py) showed on the way here: a memory round trip costs ~2 us at this size, the previous
+// layout (8 waves, two terms per wave back to back, 64-env groups) walked ~6 of them in a row (24 us); with one item per wave the
+// critical path became the SLOWEST item's instruction count -- the force-history terms evaluated 8 padded slots x 4 history slots
+// with a square root each (9.7 us for undesired_contacts against 2 us for a joint sum) -- hence exact trip counts and one square
+// root per body (max_hist_force), and the end of the step moved out of the kernel (step_tail: 4.9 us of fence + ticket).
+__global__ void __launch_bounds__(64 * IMX_TR_MAX_WAVES)
+k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame, int G, int defer_tail) {
+    extern __shared__ int32_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const int64_t grp = blockIdx.x;
+    const int64_t e = grp * G + lane;
+    const bool live = lane < G && e < N;
+    const int64_t ec = live ? e : min(grp * G, N - 1);  // dead lanes compute on a valid env of the group (no extra cache lines), never store
+    const int J = P.J, Bn = P.B, H = P.H, A = P.A;
+    const int nterm = P.nterm, nrew = P.nrew;
+    const int32_t* __restrict__ W = P.w;  // term tables: wave-uniform addresses -> scalar loads (L2-resident, a few KB)
+    IMX_STAMP(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) Bf.counters[2] += 1;  // step counter (keys the noise streams of the kernels that follow)
+    // LDS: [termination values: nterm x 64 u32 (bit 0 value, bit 1 time-out term)][f: nrew x 64][es: nrew x 64][val: nrew x 64];
+    // every slot is written by exactly one wave before the barrier that publishes it: no zero fill, no atomics
+    uint32_t* s_tv = reinterpret_cast<uint32_t*>(smem);
+    float* s_f = reinterpret_cast<float*>(s_tv + (nterm > 0 ? nterm : 1) * 64);
+    float* s_es = s_f + nrew * 64;
+    float* s_val = s_es + nrew * 64;
+
+    // -- phase 0: everything that needs no table is issued at once: root state, and the episodic sum of this wave's first reward item
+    const int first_rew = wv >= nterm ? wv - nterm : wv - nterm + ((nterm - wv + NW - 1) / NW) * NW;  // first item >= nterm of this wave
+    const float es_first = (live && first_rew < nrew) ? Bf.episode_sums[(size_t)first_rew * N + e] : 0.0f;
+    const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[ec];
+    const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+    const float lwx = S.root_lin_vel_w[ec * 3], lwy = S.root_lin_vel_w[ec * 3 + 1], lwz = S.root_lin_vel_w[ec * 3 + 2];
+    const float awx = S.root_ang_vel_w[ec * 3], awy = S.root_ang_vel_w[ec * 3 + 1], awz = S.root_ang_vel_w[ec * 3 + 2];
+    const int64_t ep = Bf.episode_length_buf[ec] + 1;  // manager_based_rl_env.py:200
+    const float cmdx = P.CMD > 0 ? S.command[ec * P.CMD + 0] : 0.0f;
+    const float cmdy = P.CMD > 1 ? S.command[ec * P.CMD + 1] : 0.0f;
+    const float cmdz = P.CMD > 2 ? S.command[ec * P.CMD + 2] : 0.0f;
+    float lbx, lby, lbz, abx, aby, abz, pgx, pgy, pgz;
+    quat_rotate_inverse(qw, qx, qy, qz, lwx, lwy, lwz, lbx, lby, lbz);
+    quat_rotate_inverse(qw, qx, qy, qz, awx, awy, awz, abx, aby, abz);
+    quat_rotate_inverse(qw, qx, qy, qz, P.gx, P.gy, P.gz, pgx, pgy, pgz);
+
+    // -- the env's frame table for the observation kernel of the same step (what k_frame writes: same functions, same inputs, so
+    //    bit-identical); the last wave has the fewest items
+    if (frame && wv == NW - 1 && live) {
+        float4 o[5];
+        o[0] = make_float4(lbx, lby, lbz, abx);
+        o[1] = make_float4(aby, abz, pgx, pgy);
+        o[2] = make_float4(pgz, S.root_pos_w[e * 3], S.root_pos_w[e * 3 + 1], S.root_pos_w[e * 3 + 2]);
+        o[3] = q4;
+        o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, o[4].x, o[4].y);
+        float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] = o[k];
+    }
+    IMX_STAMP(1);
+    IMX_STAMP(2);
+
+    // -- phase 1: one item per trip.  TerminationManager.compute (termination_manager.py:151-174) / the reward functions
+    const bool moving = sqrtf(cmdx * cmdx + cmdy * cmdy) > 0.1f;  // torch.norm(cmd[:, :2]) > 0.1
+    for (int item = wv; item < nterm + nrew; item += NW) {
+        if (item < nterm) {
+            const int k = item;
+            const int32_t* r = W + P.term_off + k * IMX_REC_WORDS;
+            const int op = r[IMX_R_OP];
+            const int n = r[IMX_R_NIDS];
+            const int32_t* ids = W + (op == IMX_T_COMMAND_RESAMPLE ? 0 : r[IMX_R_IDS_OFF]);
+            const float p0 = f_of(r[IMX_R_P0]), p1 = f_of(r[IMX_R_P1]);
+            bool v = false;
+            switch (op) {
+                case IMX_T_TIME_OUT: v = ep >= (int64_t)P.max_ep_len; break;
+                case IMX_T_ILLEGAL_CONTACT:
+                    v = any_ids(ids, n, [&](int b) { return max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0; });
+                    break;
+                case IMX_T_JOINT_POS_MANUAL_LIMIT:
+                    v = any_ids(ids, n, [&](int j) { const float q = S.joint_pos[ec * J + j]; return (q > p1) || (q < p0); });
+                    break;
+                case IMX_T_BAD_ORIENTATION: v = fabsf(acosf(-pgz)) > p0; break;
+                case IMX_T_ROOT_HEIGHT_BELOW_MIN: v = S.root_pos_w[ec * 3 + 2] < p0; break;
+                case IMX_T_JOINT_VEL_LIMIT:
+                    v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > S.soft_joint_vel_limits[ec * J + j]; });
+                    break;
+                case IMX_T_JOINT_VEL_MANUAL_LIMIT:
+                    v = any_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]) > p0; });
+                    break;
+                case IMX_T_JOINT_EFFORT_LIMIT:  // torch.isclose(computed, applied): |a-b| <= atol + rtol*|b|
+                    v = any_ids(ids, n, [&](int j) {
+                        const float a = S.computed_torque[ec * J + j], b = S.applied_torque[ec * J + j];
+                        return fabsf(a - b) <= 1.0e-8f + 1.0e-5f * fabsf(b);
+                    });
+                    break;
+                case IMX_T_TERRAIN_OUT_OF_BOUNDS:
+                    v = (fabsf(S.root_pos_w[ec * 3]) > p0) || (fabsf(S.root_pos_w[ec * 3 + 1]) > p1);
+                    break;
+                case IMX_T_EXTERNAL: v = S.ext_term[ec * (int64_t)P.w[IMX_H_NEXT_TERM] + r[IMX_R_AUX0]] != 0; break;
+                case IMX_T_COMMAND_RESAMPLE:  // (time_left <= step_dt) & (command_counter == num_resamples)
+                    v = (S.command_time_left[ec] <= p0) && (S.command_counter[ec] == (int64_t)n);
+                    break;
+                default: break;
+            }
+            s_tv[k * 64 + lane] = (v ? 1u : 0u) | (r[IMX_R_WEIGHT] ? 2u : 0u);  // bit 1: a time-out term (termination_manager.py:166-169)
+            continue;
+        }
+        const int k = item - nterm;
+        const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
+        const float es0 = k == first_rew ? es_first : (live ? Bf.episode_sums[(size_t)k * N + e] : 0.0f);
+        float f = 0.0f;
+        if (f_of(r[IMX_R_WEIGHT]) != 0.0f) {  // a zero-weight term is not evaluated (reward_manager.py:145)
+            const int op = r[IMX_R_OP];
+            const int n = r[IMX_R_NIDS];
+            const int32_t* ids = W + r[IMX_R_IDS_OFF];
+            const float p0 = f_of(r[IMX_R_P0]);
+            switch (op) {
+                // IS_ALIVE / IS_TERMINATED / IS_TERMINATED_TERM need the termination results: phase 2
+                case IMX_W_LIN_VEL_Z_L2: f = lbz * lbz; break;
+                case IMX_W_ANG_VEL_XY_L2: f = abx * abx + aby * aby; break;
+                case IMX_W_FLAT_ORIENTATION_L2: f = pgx * pgx + pgy * pgy; break;
+                case IMX_W_BASE_HEIGHT_L2: { const float d = S.root_pos_w[ec * 3 + 2] - p0; f = d * d; } break;
+                case IMX_W_JOINT_TORQUES_L2:
+                    f = sum_ids(ids, n, [&](int j) { const float x = S.applied_torque[ec * J + j]; return x * x; });
+                    break;
+                case IMX_W_JOINT_VEL_L1: f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_vel[ec * J + j]); }); break;
+                case IMX_W_JOINT_VEL_L2:
+                    f = sum_ids(ids, n, [&](int j) { const float x = S.joint_vel[ec * J + j]; return x * x; });
+                    break;
+                case IMX_W_JOINT_ACC_L2:
+                    f = sum_ids(ids, n, [&](int j) { const float x = S.joint_acc[ec * J + j]; return x * x; });
+                    break;
+                case IMX_W_JOINT_DEVIATION_L1:
+                    f = sum_ids(ids, n, [&](int j) { return fabsf(S.joint_pos[ec * J + j] - S.default_joint_pos[ec * J + j]); });
+                    break;
+                case IMX_W_JOINT_POS_LIMITS:
+                    f = sum_ids(ids, n, [&](int j) {
+                        const float q = S.joint_pos[ec * J + j];
+                        const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[ec * J + j];
+                        float o = -fminf(q - lim.x, 0.0f);
+                        o += fmaxf(q - lim.y, 0.0f);
+                        return o;
+                    });
+                    break;
+                case IMX_W_JOINT_VEL_LIMITS:
+                    f = sum_ids(ids, n, [&](int j) {
+                        const float o = fabsf(S.joint_vel[ec * J + j]) - S.soft_joint_vel_limits[ec * J + j] * p0;
+                        return fminf(fmaxf(o, 0.0f), 1.0f);
+                    });
+                    break;
+                case IMX_W_APPLIED_TORQUE_LIMITS:
+                    f = sum_ids(ids, n, [&](int j) { return fabsf(S.applied_torque[ec * J + j] - S.computed_torque[ec * J + j]); });
+                    break;
+                case IMX_W_ACTION_RATE_L2:
+                    f = sum_range(A, [&](int i) { const float d = Bf.action[ec * A + i] - Bf.prev_action[ec * A + i]; return d * d; });
+                    break;
+                case IMX_W_ACTION_L2:
+                    f = sum_range(A, [&](int i) { const float a = Bf.action[ec * A + i]; return a * a; });
+                    break;
+                case IMX_W_UNDESIRED_CONTACTS:
+                    f = sum_ids(ids, n, [&](int b) { return (max_hist_force(S.net_forces_w_history, ec, H, Bn, b) > p0) ? 1.0f : 0.0f; });
+                    break;
+                case IMX_W_CONTACT_FORCES:
+                    f = sum_ids(ids, n, [&](int b) { return fmaxf(max_hist_force(S.net_forces_w_history, ec, H, Bn, b) - p0, 0.0f); });
+                    break;
+                case IMX_W_TRACK_LIN_VEL_XY_EXP: {
+                    const float ex = cmdx - lbx, ey = cmdy - lby;
+                    f = expf(-(ex * ex + ey * ey) / p0);  // p0 = std**2
+                } break;
+                case IMX_W_TRACK_ANG_VEL_Z_EXP: { const float ez = cmdz - abz; f = expf(-(ez * ez) / p0); } break;
+                case IMX_W_FEET_AIR_TIME: {
+                    // first_contact = (cct > 0) * (cct < dt + abs_tol); p1 = float32(step_dt + 1e-8)
+                    const float p1 = f_of(r[IMX_R_P1]);
+                    f = sum_ids(ids, n, [&](int b) {
+                        const float cct = S.current_contact_time[ec * Bn + b];
+                        const float fc = (cct > 0.0f && cct < p1) ? 1.0f : 0.0f;
+                        return (S.last_air_time[ec * Bn + b] - p0) * fc;
+                    });
+                    f *= moving ? 1.0f : 0.0f;
+                } break;
+                case IMX_W_FEET_AIR_TIME_POSITIVE_BIPED: {
+                    int n_contact = 0;
+                    float mn = __builtin_huge_valf();
+                    for (int i = 0; i < n; ++i) n_contact += (S.current_contact_time[ec * Bn + ids[i]] > 0.0f) ? 1 : 0;
+                    for (int i = 0; i < n; ++i) {
+                        const float ct = S.current_contact_time[ec * Bn + ids[i]], at = S.current_air_time[ec * Bn + ids[i]];
+                        const float in_mode = (ct > 0.0f) ? ct : at;
+                        mn = fminf(mn, (n_contact == 1) ? in_mode : 0.0f);
+                    }
+                    f = fminf(mn, p0);
+                    f *= moving ? 1.0f : 0.0f;
+                } break;
+                case IMX_W_FEET_SLIDE: {
+                    const int32_t* ids2 = W + r[IMX_R_IDS2_OFF];
+                    for (int i = 0; i < n; ++i) {
+                        const float c = (max_hist_force(S.net_forces_w_history, ec, H, Bn, ids[i]) > 1.0f) ? 1.0f : 0.0f;
+                        const float* v = S.body_lin_vel_w + ((size_t)ec * P.NB + ids2[i]) * 3;
+                        f += sqrtf(v[0] * v[0] + v[1] * v[1]) * c;
+                    }
+                } break;
+                case IMX_W_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {
+                    float yw, yz, vx, vy, vz;
+                    yaw_quat_wz(qw, qx, qy, qz, yw, yz);
+                    quat_rotate_inverse(yw, 0.0f, 0.0f, yz, lwx, lwy, lwz, vx, vy, vz);
+                    const float ex = cmdx - vx, ey = cmdy - vy;
+                    f = expf(-(ex * ex + ey * ey) / p0);
+                } break;
+                case IMX_W_TRACK_ANG_VEL_Z_WORLD_EXP: { const float ez = cmdz - awz; f = expf(-(ez * ez) / p0); } break;
+                case IMX_W_JOINT_POS_TARGET_L2:
+                    f = sum_ids(ids, n, [&](int j) { const float d = wrap_to_pi(S.joint_pos[ec * J + j]) - p0; return d * d; });
+                    break;
+                case IMX_W_EXTERNAL: f = S.ext_reward[ec * (int64_t)P.w[IMX_H_NEXT_REW] + r[IMX_R_AUX0]]; break;
+                case IMX_W_BODY_LIN_ACC_L2:  // sum over bodies of ||body_lin_acc_w|| (rewards.py:125-128)
+                    f = sum_ids(ids, n, [&](int b) {
+                        const float* a = S.body_lin_acc_w + ((size_t)ec * P.NB + b) * 3;
+                        return norm3(a[0], a[1], a[2]);
+                    });
+                    break;
+                default: break;
+            }
+        }
+        s_f[k * 64 + lane] = f;
+        s_es[k * 64 + lane] = es0;
+    }
+    IMX_STAMP(3);
+    __syncthreads();
+    IMX_STAMP(4);
+
+    // -- phase 2: every termination is known
+    uint32_t term_bits = 0u, trunc_mask = 0u;
+    for (int k = 0; k < nterm; ++k) {
+        const uint32_t x = s_tv[k * 64 + lane];
+        term_bits |= (x & 1u) << k;
+        trunc_mask |= ((x >> 1) & 1u) << k;
+    }
+    const bool truncated = (term_bits & trunc_mask) != 0u, terminated = (term_bits & ~trunc_mask) != 0u;
+    const bool reset = live && (terminated || truncated);
+    // RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; sums += value; step_reward = value/dt
+    const float dt = P.step_dt;
+    for (int k = wv; k < nrew; k += NW) {
+        const int32_t* r = W + P.rew_off + k * IMX_REC_WORDS;
+        const float weight = f_of(r[IMX_R_WEIGHT]);
+        const float es0 = s_es[k * 64 + lane];
+        float es = es0, value = 0.0f;
+        if (weight != 0.0f) {
+            float f = s_f[k * 64 + lane];
+            const int op = r[IMX_R_OP];
+            if (op == IMX_W_IS_ALIVE) f = terminated ? 0.0f : 1.0f;
+            if (op == IMX_W_IS_TERMINATED) f = terminated ? 1.0f : 0.0f;
+            if (op == IMX_W_IS_TERMINATED_TERM) {
+                const int n = r[IMX_R_NIDS];
+                const int32_t* ids = W + r[IMX_R_IDS_OFF];
+                float sum = 0.0f;
+                for (int i = 0; i < n; ++i) sum += ((term_bits >> ids[i]) & 1u) ? 1.0f : 0.0f;
+                f = sum * (truncated ? 0.0f : 1.0f);
+            }
+            value = f * weight * dt;
+            es = es0 + value;
+            if (live) Bf.step_reward[(size_t)e * nrew + k] = value / dt;
+        }
+        // (a skipped term leaves step_reward as it was and still takes part in the reset / log pass, reward_manager.py:100-126,145)
+        s_val[k * 64 + lane] = value;
+        if (live && (weight != 0.0f || reset)) Bf.episode_sums[(size_t)k * N + e] = reset ? 0.0f : es;
+        // RewardManager.reset log (reward_manager.py:115-121): mean over reset envs of the episodic sum
+        const float part = wave_sum(reset ? es : 0.0f);
+        if (lane == 0) sc.log_part[grp * nrew + k] = part;
+    }
+    // termination bookkeeping by the waves from the far end (wave 0 is busy below)
+    for (int k = NW - 1 - wv; k < nterm; k += NW) {
+        const bool v = (term_bits >> k) & 1u;
+        if (live) Bf.term_dones[(size_t)k * N + e] = v ? 1 : 0;
+        // TerminationManager.reset log (termination_manager.py:142-144): count_nonzero(term_dones[reset ids])
+        const int c = wave_sum_i((reset && v) ? 1 : 0);
+        if (lane == 0) sc.term_part[grp * nterm + k] = c;
+    }
+    IMX_STAMP(5);
+    __syncthreads();
+    IMX_STAMP(6);
+
+    // -- phase 3
+    if (wv == 0) {
+        float reward = 0.0f;
+        for (int k = 0; k < nrew; ++k) reward += s_val[k * 64 + lane];  // term order (a skipped term holds +0: x + 0 == x bit for bit)
+        // -- outputs + manager-side _reset_idx (manager_based_rl_env.py:347-392)
+        if (live) {
+            Bf.reward_buf[e] = reward;
+            Bf.terminated[e] = terminated ? 1 : 0;
+            Bf.truncated[e] = truncated ? 1 : 0;
+            Bf.reset_buf[e] = reset ? 1 : 0;
+            Bf.episode_length_buf[e] = reset ? 0 : ep;
+            if (reset)
+                for (int i = 0; i < A; ++i) {  // ActionManager.reset (action_manager.py:306-316)
+                    Bf.action[e * A + i] = 0.0f;
+                    Bf.prev_action[e * A + i] = 0.0f;
+                }
+        }
+        // ordered compaction inside the group: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
+        const unsigned long long ballot = __ballot(reset);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (reset) sc.ids_local[grp * 64 + before] = lane;
+        if (lane == 0) sc.wave_cnt[grp] = __popcll(ballot);
+    }
+
+    IMX_STAMP(7);
+    if (defer_tail) return;  // imx_observations of the same step finishes (step_tail in an extra workgroup of k_obs)
+    // producer side (cdna_hip_programming.md G16, R1): every storing wave drains its stores, the block meets at the
+    // barrier, ONE lane releases at agent scope and takes the ticket
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = atomicAdd(&Bf.counters[1], 1);
+        s_last = (ticket == (int)gridDim.x - 1);
+        if (s_last) {  // consumer side: one agent-scope acquire, completed before the barrier releases the readers
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            Bf.counters[1] = 0;  // re-arm the ticket
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    step_tail(P, N, Bf, sc, G);
 }
 
 // ------------------------------------------------------------------------------------------------- observations
@@ -673,122 +763,163 @@ IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& 
     *o = vp;
 }
 
-#ifdef IMX_TRACE  // tools/trace_kobs.py only: per-wave start / end stamps (100 MHz wall clock) and placement; never in libimx.so
-__device__ uint64_t* g_trace = nullptr;
-extern "C" int imx_debug_trace(uint64_t* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)); }
-#endif
 
 template <bool GENERAL_RAYS>
 __global__ void __launch_bounds__(256)
 k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
-      const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out) {
+      const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G) {
+    // One workgroup per env.  (A resident grid walking the envs -- sized to what the chip holds at once -- was measured and dropped:
+    // the loop costs 13 more VGPRs, i.e. one wave per SIMD less, and three uneven rounds: 35 us against 29.)
     const int64_t e = blockIdx.x;
+    if (e == N) {  // the extra workgroup: the step tail k_term_rew deferred (its partials are complete: kernel boundary)
+        step_tail(P, N, Bf, sc, tail_G);
+        return;
+    }
     const int32_t* __restrict__ W = P.w;
-    const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
     const uint32_t step = (uint32_t)Bf.counters[2];
-    float pz = es[11];
-    const float yw = es[16], yz = es[17];
-    float px = es[9], py = es[10];
     const bool fill_all = (corrupt & 2) != 0;
     const bool keep_all_hits = (corrupt & 8) != 0;
     corrupt &= 1;
+    extern __shared__ float s_hz[];  // R hit heights of this env
+    const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
+    float pz = es[11];
+    const float yw = es[16], yz = es[17];
+    float px = es[9], py = es[10];
     // -- the height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide
     //    whether this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  The
     //    decision is a function of the env's state only, so every lane of the block takes the same one from the same (scalar) loads;
     //    the state is double-buffered on the step counter: lanes read slot step&1, thread 0 writes the other -- a second call within
     //    the same step (ObservationManager.compute() by user code) finds the same inputs and repeats the same outputs.
+#ifdef IMX_TRACE
+    uint64_t trace_tp = 0;
+#endif
     bool cast = true, cache_z = false;
     if (P.scan_stateful) {
-        const float* st = Bf.scan_state + ((size_t)(step & 1u) * N + e) * 8;
-        float ts = st[0], last = st[1], drx = st[2], dry = st[3], drz = st[4], pz_data = st[5];
-        bool outdated = st[6] != 0.0f;
-        for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
-        outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
-        if (fill_all || Bf.reset_buf[e]) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
-            ts = 0.0f; last = 0.0f; outdated = true;
-            if (Bf.scan_drift_feed) {
-                drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+        // One row per env {timestamp, last update, drift xyz, data.pos_w z, outdated, step stamp}: wave 0 reads it (with the step counter,
+        // the reset flag and everything else the block needs: no load here depends on another), advances it once per step -- the
+        // stamp tells a repeated call within the same step (ObservationManager.compute() by user code), which repeats the decision
+        // instead of advancing the clock again --, thread 0 writes it back, and the block's other waves take the outcome from LDS.
+        __shared__ float s_scan[8];
+        if (threadIdx.x < 64) {
+            float* row = Bf.scan_state + (size_t)e * 8;
+            float ts = row[0], last = row[1], drx = row[2], dry = row[3], drz = row[4], pz_data = row[5];
+            bool outdated = row[6] != 0.0f;
+            const bool repeat = __float_as_uint(row[7]) == step + 1u;  // stamp = step + 1 (0 = never)
+            const bool was_reset = fill_all || Bf.reset_buf[e];
+            if (!repeat) {
+                for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
+                outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
+                if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
+                    ts = 0.0f; last = 0.0f; outdated = true;
+                    if (Bf.scan_drift_feed) {
+                        drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+                    } else {
+                        const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
+                        drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
+                        dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
+                        drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+                    }
+                }
             } else {
-                const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
-                drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
-                dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
-                drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+                outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
+            }
+            float keep = 0.0f;
+            if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
+                pz_data = pz + drz;
+                last = ts;
+                float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
+                for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
+                keep = (keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period)) ? 1.0f : 0.0f;
+            }
+            if (threadIdx.x == 0) {
+                float4* o = reinterpret_cast<float4*>(row);
+                o[0] = make_float4(ts, last, drx, dry);
+                o[1] = make_float4(drz, pz_data, 0.0f, __uint_as_float(step + 1u));
+                s_scan[0] = outdated ? 1.0f : 0.0f; s_scan[1] = keep; s_scan[2] = drx; s_scan[3] = dry; s_scan[4] = pz_data;
             }
         }
-        cast = outdated;
-        if (cast) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
-            px += drx; py += dry; pz += drz;
-            pz_data = pz;
-            last = ts;
-            float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
-            for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
-            cache_z = keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period);
-        } else {
-            pz = pz_data;  // data.pos_w of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
-        }
-        if (threadIdx.x == 0) {
-            float4* o = reinterpret_cast<float4*>(Bf.scan_state + ((size_t)((step & 1u) ^ 1u) * N + e) * 8);
-            o[0] = make_float4(ts, last, drx, dry);
-            o[1] = make_float4(drz, pz_data, 0.0f, 0.0f);
-        }
+        __syncthreads();
+#ifdef IMX_TRACE
+        trace_tp = wall_clock64();
+#endif
+        cast = s_scan[0] != 0.0f;
+        cache_z = s_scan[1] != 0.0f;
+        if (cast) { px += s_scan[2]; py += s_scan[3]; }
+        pz = s_scan[4];  // data.pos_w z of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
     }
 #ifdef IMX_TRACE
     const uint64_t trace_t0 = wall_clock64();
+    uint64_t trace_t1 = 0, trace_t2 = 0;
 #endif
+    // -- phase A: the env's rays.  RayCaster._update_buffers_impl (ray_caster.py:242-260): ray j of the scanner -> hit height into LDS.
+    //    Kept apart from the column loop below on purpose: what limits this kernel is how many waves a SIMD can hold (wave life x
+    //    residency, tools/trace_kobs.py), i.e. its register count -- a ray lane carries the ray and one cell's data, a column lane its
+    //    16-word column record, never both.
+    if (P.R > 0) {
+        const float* __restrict__ ray_local = reinterpret_cast<const float*>(W + P.ray_off);
+        for (int j = threadIdx.x; j < P.R; j += blockDim.x) {
+            float hz;
+            if (cast) {
+                const float lx = ray_local[3 * j], ly = ray_local[3 * j + 1], lz = ray_local[3 * j + 2];
+                float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
+                if (P.ray_yaw_only) {
+                    quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
+                } else {  // ray_caster.py:249-252: full orientation for starts and directions
+                    quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
+                    quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
+                }
+                sx += px; sy += py; sz += pz;
+                float t;
+                int32_t face;
+                const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
+                                              : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
+                hz = hit ? sz + t * dz : __builtin_huge_valf();  // kernels.py:69; misses stay +inf (ops.py:70)
+                if (ray_hits_out) {
+                    float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
+                    o[0] = hit ? sx + t * dx : __builtin_huge_valf();
+                    o[1] = hit ? sy + t * dy : __builtin_huge_valf();
+                    o[2] = hz;
+                }
+                if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
+            } else {
+                hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
+            }
+            s_hz[j] = hz;
+        }
+#ifdef IMX_TRACE
+        trace_t1 = wall_clock64();
+#endif
+        __syncthreads();
+#ifdef IMX_TRACE
+        trace_t2 = wall_clock64();
+#endif
+    }
+    // -- phase B: the observation columns (ObservationManager.compute_group, observation_manager.py:260-335)
     for (int i = threadIdx.x; i < P.DC; i += blockDim.x) {
         const XCol x = load_xcol(W, P.xcol_off, i);
         const int op = x.a.y, j = x.a.z;
-        float v = 0.0f;
-        switch (op) {
-            case IMX_O_HEIGHT_SCAN: {
-                // RayCaster._update_buffers_impl (ray_caster.py:242-260) + height_scan (observations.py:165-173)
-                float hz;
-                if (cast) {
-                    const float lx = f_of(x.c.w), ly = f_of(x.d.x), lz = f_of(x.d.y);
-                    float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
-                    if (P.ray_yaw_only) {
-                        quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
-                    } else {  // ray_caster.py:249-252: full orientation for starts and directions
-                        quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
-                        quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
-                    }
-                    sx += px; sy += py; sz += pz;
-                    float t;
-                    int32_t face;
-                    float hx, hy;
-                    const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
-                                                  : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
-                    if (hit) {
-                        hx = sx + t * dx; hy = sy + t * dy; hz = sz + t * dz;  // kernels.py:69
-                    } else {
-                        hx = hy = hz = __builtin_huge_valf();  // ops.py:70
-                    }
-                    if (ray_hits_out) {
-                        float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
-                        o[0] = hx; o[1] = hy; o[2] = hz;
-                    }
-                    if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
-                } else {
-                    hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
-                }
-                v = pz - hz - f_of(x.b.x);
-                // further height_scan terms on the same sensor (another group, another offset / noise / clip): same hit, own post-processing
-                for (int nx = x.c.z; nx != 0;) {
-                    const XCol tw = load_xcol(W, P.xcol_off, nx - 1);
-                    obs_finish(P, Bf, tw, nx - 1, pz - hz - f_of(tw.b.x), e, corrupt, fill_all, noise_u, seed, step);
-                    nx = tw.c.z;
-                }
-            } break;
-            default: v = obs_plain_value(P, S, Bf, es, e, x); break;
+        float v;
+        if (op == IMX_O_HEIGHT_SCAN) {  // height_scan (observations.py:165-173): sensor.data.pos_w z - hit z - offset
+            const float hz = s_hz[j];
+            v = pz - hz - f_of(x.b.x);
+            // further height_scan terms on the same sensor (another group, another offset / noise / clip): same hit, own post-processing
+            for (int nx = x.c.z; nx != 0;) {
+                const XCol tw = load_xcol(W, P.xcol_off, nx - 1);
+                obs_finish(P, Bf, tw, nx - 1, pz - hz - f_of(tw.b.x), e, corrupt, fill_all, noise_u, seed, step);
+                nx = tw.c.z;
+            }
+        } else {
+            v = obs_plain_value(P, S, Bf, es, e, x);
         }
         obs_finish(P, Bf, x, i, v, e, corrupt, fill_all, noise_u, seed, step);
     }
 #ifdef IMX_TRACE
     if (g_trace && (threadIdx.x & 63) == 0) {
-        uint64_t* t = g_trace + ((size_t)e * 4 + (threadIdx.x >> 6)) * 4;
+        uint64_t* t = g_trace + ((size_t)e * 4 + (threadIdx.x >> 6)) * 8;
         t[0] = trace_t0; t[1] = wall_clock64();
         t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID (wave/simd/cu/sh/se ids)
         t[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+        t[4] = trace_t1; t[5] = trace_t2; t[6] = trace_tp;
     }
 #endif
 }
@@ -854,7 +985,7 @@ extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float
 }
 
 extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const imx_state_t* st,
-                                        const imx_buffers_t* bf, imx_stream_t stream) {
+                                        const imx_buffers_t* bf, int flags, imx_stream_t stream) {
     if (check_common(plan, N, st, bf)) return 1;
     IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w, "root state missing");
     IMX_REQUIRE(bf->episode_length_buf && bf->reward_buf && bf->episode_sums && bf->step_reward && bf->term_dones &&
@@ -904,18 +1035,17 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
         }
     }
     if (plan->CMD > 0 && !st->command) IMX_FAIL("command tensor missing");
-    const int G = N <= 8192 ? 32 : 64;  // envs per workgroup (see k_term_rew)
+    const int G = step_group_size(N);
     const unsigned grid = (unsigned)((N + G - 1) / G);
     StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
-    const size_t lds = (size_t)(plan->nrew > 0 ? plan->nrew : 1) * 64 * sizeof(float);
+    // one wave per work item (termination or reward term) up to 16 waves; more items go round-robin
+    const int items = plan->nterm + plan->nrew;
+    const int NW = items < 2 ? 2 : (items > IMX_TR_MAX_WAVES ? IMX_TR_MAX_WAVES : items);
+    const size_t lds = ((size_t)(plan->nterm > 0 ? plan->nterm : 1) * 64 + 3 * (size_t)(plan->nrew > 0 ? plan->nrew : 1) * 64) * 4;
     // with the root position at hand the kernel also leaves the frame table imx_observations needs (flag 4 there skips k_frame)
     float* frame = st->root_pos_w ? reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N)) : nullptr;
-    if (G == 32)
-        hipLaunchKernelGGL(k_term_rew<32>, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
-                           *bf, sc, frame);
-    else
-        hipLaunchKernelGGL(k_term_rew<64>, dim3(grid), dim3(64 * IMX_TR_WAVES), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st,
-                           *bf, sc, frame);
+    hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(64 * NW), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, sc, frame, G,
+                       flags & 1);
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -934,7 +1064,7 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
             IMX_REQUIRE(extra[g - 1], "imx_observations: the plan has %d observation groups but obs_extra%d is NULL", plan->ngroups, g);
     }
     IMX_REQUIRE(!plan->scan_stateful || (bf->scan_state && bf->scan_hit_z && bf->reset_buf),
-                "imx_observations: the height scanner has an update period / drift range: scan_state (2,N,8), scan_hit_z (N,R) and reset_buf are required");
+                "imx_observations: the height scanner has an update period / drift range: scan_state (N,8), scan_hit_z (N,R) and reset_buf are required");
     IMX_REQUIRE(plan->MS == 0 || (bf->mod_state && bf->reset_buf),
                 "imx_observations: the plan has stateful observation modifiers: mod_state (N x %d floats) and reset_buf are required", plan->MS);
     const auto& w = plan->host;
@@ -969,12 +1099,23 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
         hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, frame);
     // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
     const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
+    // bit 4: finish the step tail imx_terminations_rewards (flags bit 0) left to this call -- one extra workgroup
+    const bool tail = (enable_corruption & 16) != 0;
+    StepScratch sc{};
+    int tail_G = 0;
+    if (tail) {
+        IMX_REQUIRE(bf->reset_env_ids && bf->log_out, "imx_observations: finishing the step tail needs reset_env_ids and log_out");
+        sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
+        tail_G = step_group_size(N);
+    }
+    const size_t lds = (size_t)(pv.R > 0 ? pv.R : 1) * 4;
+    const unsigned grid = (unsigned)N + (tail ? 1u : 0u);
     if (vertical)
-        hipLaunchKernelGGL(k_obs<false>, dim3((unsigned)N), dim3(bs), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame,
-                           noise_u_d, seed, enable_corruption, ray_hits_out_d);
+        hipLaunchKernelGGL(k_obs<false>, dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv,
+                           frame, noise_u_d, seed, enable_corruption, ray_hits_out_d, sc, tail_G);
     else
-        hipLaunchKernelGGL(k_obs<true>, dim3((unsigned)N), dim3(bs), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame,
-                           noise_u_d, seed, enable_corruption, ray_hits_out_d);
+        hipLaunchKernelGGL(k_obs<true>, dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv,
+                           frame, noise_u_d, seed, enable_corruption, ray_hits_out_d, sc, tail_G);
     IMX_HIP(hipGetLastError());
     return 0;
 }

@@ -67,7 +67,8 @@ class TerrainMesh:
                                     ctypes.byref(self._h)))
         info = (ctypes.c_int64 * 8)()
         check(lib().imx_mesh_info(self._h, info))
-        self.nx, self.ny, self.num_triangles, self.num_refs, self.max_refs = (int(info[i]) for i in range(5))
+        self.nx, self.ny, self.num_triangles, self.num_refs = (int(info[i]) for i in range(4))
+        self.max_refs, self.num_flat_cells = int(info[4]) & 0xFFFFFFFF, int(info[4]) >> 32  # FLAT: general cells answered by their descriptor
         self.num_lattice_cells, self.num_general_cells = int(info[5]), int(info[6])
         self.num_vertices = v.shape[0]
 
@@ -523,14 +524,15 @@ class ManagerBasedRLEnv:
         self._ray_hits = None
         self.reward_buf = self._reward_buf
         self.obs_buf = {g.name: t for g, t in zip(plan.obs_groups, self._obs_groups)}
-        # height scanner as a SensorBase (update_period gating, drift): double-buffered per-env {timestamp, last update, drift xyz,
-        # data.pos_w z, outdated} + the hit heights of envs that skip an update; sensors start outdated (sensor_base.py:_initialize_impl)
+        # height scanner as a SensorBase (update_period gating, drift): per env {timestamp, last update, drift xyz, data.pos_w z,
+        # outdated, step stamp} + the hit heights of envs that skip an update; sensors start outdated (sensor_base.py:_initialize_impl)
         self._scan_state = self._scan_hit_z = None
         self._scan_drift_feed: torch.Tensor | None = None  # parity runs: (N,3) drift values taken at a sensor reset
+        self.defer_step_tail = True  # the step's tail (ordered reset ids, Episode_* log) rides in the observation launch (include/imx.h)
         self.scanner_keep_all_hits = False  # keep every env's hit heights (set before overwriting the sensor timestamps by hand)
         if plan.scan_stateful:
-            self._scan_state = z(2, N, 8)
-            self._scan_state[:, :, 6] = 1.0
+            self._scan_state = z(N, 8)
+            self._scan_state[:, 6] = 1.0
             self._scan_hit_z = z(N, plan.num_rays)
 
         blob = np.ascontiguousarray(plan.blob, np.int32)
@@ -741,7 +743,7 @@ class ManagerBasedRLEnv:
                 self._ext_obs[:, c:c + term.dim] = val.reshape(self.num_envs, -1)
                 c += term.dim
 
-    def _compute_observations(self, fill_history: bool = False, frame_current: bool = False) -> torch.Tensor:
+    def _compute_observations(self, fill_history: bool = False, frame_current: bool = False, finish_step_tail: bool = False) -> torch.Tensor:
         if self._ext_funcs["obs"]:
             self._eval_external("obs")
         hits = None
@@ -754,7 +756,7 @@ class ManagerBasedRLEnv:
             self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
             self.terrain.handle if self.terrain is not None else None, _lib.ptr(self._noise_u), self.noise_seed,
             (1 if self.plan.enable_corruption else 0) | (2 if fill_history else 0) | (4 if frame_current else 0)
-            | (8 if self.scanner_keep_all_hits else 0), hits, _lib.current_stream(self.device)))
+            | (8 if self.scanner_keep_all_hits else 0) | (16 if finish_step_tail else 0), hits, _lib.current_stream(self.device)))
         return self._obs
 
     # ---- MDP operations ------------------------------------------------------------------------------------------
@@ -800,8 +802,10 @@ class ManagerBasedRLEnv:
         if self._ext_funcs["rew"] or self._ext_funcs["term"]:
             self._eval_external("term")
             self._eval_external("rew")
+        # flag 1: the end of the step (ordered reset ids, reset count, Episode_* log) is finished by an extra workgroup of the
+        # observation kernel below -- same stream, kernel boundary in between -- instead of a fence + ticket in this launch
         check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
-                                                 ctypes.byref(self._bufs), _lib.current_stream(self.device)))
+                                                 ctypes.byref(self._bufs), 1 if self.defer_step_tail else 0, _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
         if self.reset_events is not None:  # EventManager.apply(mode="reset", env_ids=reset_env_ids) as one masked launch
             f, w = self.feed, self.sim_writes
@@ -814,7 +818,7 @@ class ManagerBasedRLEnv:
             self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], self.reset_buf)
         # -- observations on the post-reset state (one kernel, ray-cast fused); imx_terminations_rewards left the frame table of
         #    this state snapshot behind (the feed's root state is not rewritten by the reset events: they go to sim_writes)
-        self._compute_observations(frame_current=True)
+        self._compute_observations(frame_current=True, finish_step_tail=self.defer_step_tail)
         return dict(self.obs_buf), self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     @property

@@ -661,10 +661,12 @@ class PlanCompiler:
         scan_stateful = bool(R_n > 0 and (scan_period > 0.0 or drift[0] != 0.0 or drift[1] != 0.0))
 
         # ---- assemble
-        ray_off = blob.floats(ray_local.reshape(-1)) if ray_local is not None else 0
+        # the step kernel stages words [HEADER_WORDS, end of the reward table) in LDS (id lists + termination and reward records):
+        # keep that range small -- the ray table and the observation / action records come after it
         group_off = blob.ints([x for g_ in groups for x in (g_.dim, int(g_.enable_corruption), g_.first_record, g_.num_records)])
         term_off = blob.table(term_recs)
         rew_off = blob.table(rew_recs)
+        ray_off = blob.floats(ray_local.reshape(-1)) if ray_local is not None else 0
         obs_off = blob.table(obs_recs)
         act_off = blob.table(act_recs)
         w = blob.w

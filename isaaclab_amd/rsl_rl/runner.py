@@ -67,6 +67,10 @@ class OnPolicyRunner:
         self._cur_reward_sum = torch.zeros(N, device=self.device)
         self._cur_episode_length = torch.zeros(N, device=self.device)
         self._ep_stats = torch.zeros(3, device=self.device)  # finished episodes: sum reward, sum length, count
+        # running sum of the env's extras["log"] entries over the steps of an iteration (upstream: ep_infos.append(infos["log"]) per step)
+        n_log = self.env.unwrapped._log_out.numel() if hasattr(self.env.unwrapped, "_log_out") else 1
+        self._log_accum = torch.zeros(n_log, device=self.device)
+        self._log_steps = 0
         self._obs = obs
         self._act_seed = int(train_cfg.get("seed", 42)) * 1000003 + self.gpu_global_rank
         self.collection_time = self.learn_time = 0.0
@@ -173,7 +177,8 @@ class OnPolicyRunner:
             check(L.imx_rollout_post(N, rew.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), st.values[t].data_ptr(),
                                      float(alg.gamma), bootstrap, st.rewards[t].data_ptr(), st.dones[t].data_ptr(), None,
                                      self._cur_reward_sum.data_ptr(), self._cur_episode_length.data_ptr(),
-                                     self._ep_stats.data_ptr(), stream))
+                                     self._ep_stats.data_ptr(), env._log_out.data_ptr(), self._log_accum.data_ptr(),
+                                     self._log_accum.numel(), stream))
             obs = obs_dict["policy"]
         st.step = self.num_steps_per_env
         if self._graph_capturing:

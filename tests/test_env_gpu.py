@@ -18,10 +18,14 @@ def make_env(g: Golden, **kw):
     return ManagerBasedRLEnv(g.fixture, state_feed=feed, terrain=mesh, **kw)
 
 
+@pytest.mark.parametrize("tail", ["deferred", "in_kernel"])
 @pytest.mark.parametrize("task", TASKS)
-def test_env_step_matches_reference_goldens(task):
+def test_env_step_matches_reference_goldens(task, tail):
+    """``tail``: the end of the step (ordered reset ids, reset count, Episode_* log) finished by an extra workgroup of the observation
+    launch (what env.step() does) or inside imx_terminations_rewards by its last-arriving workgroup (the stand-alone C-ABI call)."""
     g = Golden(task)
     env = make_env(g)
+    env.defer_step_tail = tail == "deferred"
     env.materialize_ray_hits = True
     N, D = g.N, g.meta["obs_dim"]
     env._noise_u = torch.zeros(N, D, device="cuda:0")
@@ -132,7 +136,7 @@ def test_full_size_against_cpu_oracle(task, N):
             from oracle.mdp_oracle import quat_apply_yaw
             from oracle.raycast import raycast_f64
 
-            ne, R = min(24, N), env.plan.num_rays
+            ne, R = min(256, N), env.plan.num_rays  # 48 k rays: lattice, FLAT and edge cells of the mixed terrain
             local = torch.from_numpy(env.plan.ray_starts_local).unsqueeze(0).repeat(ne, 1, 1)
             starts = quat_apply_yaw(cpu_feed["root_quat_w"][:ne].repeat(1, R), local) + cpu_feed["root_pos_w"][:ne].unsqueeze(1)
             dirs = torch.tensor(env.plan.ray_direction).repeat(ne * R, 1)
@@ -367,8 +371,8 @@ def test_kitchen_sink_matches_reference_golden():
     assert_close(obs_dict["critic"], g.t("reset/obs/critic"), FLOAT_TOL, "reset critic obs")
     assert_close(env._ray_hits, g.t("reset/ray_hits_w"), FLOAT_TOL, "reset sensor hits")
     # sensors that have been running for 0 / 16.5 / 30 / 5 s (fp32 timestamps): inject like the fixture generator did
-    env._scan_state[:, :, 0] = g.t("reset/scan_ts0").cuda()
-    env._scan_state[:, :, 1] = g.t("reset/scan_ts0").cuda()
+    env._scan_state[:, 0] = g.t("reset/scan_ts0").cuda()
+    env._scan_state[:, 1] = g.t("reset/scan_ts0").cuda()
     env.episode_length_buf = g.t("reset/episode_length_buf")
     stale = 0
     for k in range(g.steps):
@@ -392,7 +396,11 @@ def test_kitchen_sink_matches_reference_golden():
         for name in g.meta["reward_terms"]:
             assert_close(env.reward_manager._episode_sums[name], g.t(f"{tag}/episode_sums/{name}"), FLOAT_TOL, name)
         # the sensor: which envs refreshed (timestamps bit-exact), what they hold
-        cur = env._scan_state[(int(env._counters[2].item()) + 1) & 1].cpu()
+        cur = env._scan_state.cpu()
+        if k == 1:  # a second compute() within the step (user code) repeats the step's decision instead of advancing the sensor clock
+            before = {k_: v.clone() for k_, v in obs_dict.items()}
+            again = env.observation_manager.compute()
+            assert all(torch.equal(again[k_], before[k_]) for k_ in before) and torch.equal(env._scan_state.cpu()[:, :7], cur[:, :7])
         assert torch.equal(cur[:, 0], g.t(f"{tag}/scan_timestamp")), "sensor timestamps"
         assert torch.equal(cur[:, 1], g.t(f"{tag}/scan_timestamp_last_update")), "sensor last-update stamps"
         stale += int((cur[:, 0] != cur[:, 1]).sum())

@@ -454,9 +454,12 @@ def test_rollout_post_bootstrap_and_episode_stats(libimx):
     cur_r, cur_l = torch.rand(N, generator=g).cuda(), torch.randint(0, 50, (N,), generator=g).float().cuda()
     cr0, cl0 = cur_r.clone(), cur_l.clone()
     stats = torch.zeros(3, device="cuda")
+    log_in = torch.randn(300, generator=g).cuda()  # more entries than a workgroup has threads
+    log_acc = torch.ones(300, device="cuda")
     _lib.check(libimx.imx_rollout_post(N, rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), val.data_ptr(), 0.99, 1,
                                        rew_out.data_ptr(), dones.data_ptr(), dl.data_ptr(), cur_r.data_ptr(), cur_l.data_ptr(),
-                                       stats.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                       stats.data_ptr(), log_in.data_ptr(), log_acc.data_ptr(), 300, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(log_acc, 1.0 + log_in)  # the runner's per-iteration sum of extras["log"]
     assert_close(rew_out[:, 0], bootstrap_time_outs(rew, val, trunc, 0.99), 1e-6, "time-out bootstrap")
     d = term | trunc
     assert torch.equal(dones[:, 0].bool(), d) and torch.equal(dl, d.long())

@@ -31,14 +31,14 @@ fx, env, ntri = build_env("Isaac-Velocity-Rough-Anymal-C-v0", 4096, dev, 42, 4, 
 env.reset()
 L = _lib.lib()
 L.imx_debug_trace.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(4096 * 4 * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
 for _ in range(5):
     env._compute_observations()
 torch.cuda.synchronize()
 assert L.imx_debug_trace(buf.data_ptr()) == 0
 env._compute_observations()
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(4096, 4, 4)[:, :3]  # 3 waves per block
+t = buf.cpu().numpy().reshape(4096, 4, 8)[:, :3]  # 3 waves per block
 t0, t1 = t[..., 0].astype(np.float64), t[..., 1].astype(np.float64)
 base = t0.min()
 s, e = (t0 - base) * 0.01, (t1 - base) * 0.01  # us (100 MHz)
@@ -48,6 +48,9 @@ print("wave life us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f
     life.mean(), *np.percentile(life, [10, 50, 90, 99]), life.max()))
 for w in range(3):
     print(f"  wave {w}: mean life {life[:, w].mean():.2f} us")
+tp, tr, tb = [(t[..., k].astype(np.float64) - base) * 0.01 for k in (6, 4, 5)]
+print("phases (mean us per wave): start -> scanner state broadcast %.2f | -> rays done %.2f | barrier wait %.2f | columns %.2f" % (
+    (tp - s).mean(), (tr - tp).mean(), (tb - tr).mean(), (e - tb).mean()))
 edges = np.arange(0, e.max() + 1.0, 1.0)
 print("t(us): resident waves | blocks started in this us")
 bs = s.min(axis=1)
