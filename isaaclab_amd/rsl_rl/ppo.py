@@ -412,18 +412,51 @@ class PPO:
         return float(self._adam[0].item())
 
     def optimizer_state_dict(self) -> dict:
-        """Adam moments PER PARAMETER NAME (independent of where a parameter sits in the flat bucket) + the 8 device-side scalars."""
-        base, out = self.bucket.flat.data_ptr(), {"exp_avg": {}, "exp_avg_sq": {}, "adam_state": self._adam.clone()}
-        for name, p in self.policy.named_parameters():
-            if not p.requires_grad:
-                continue
+        """The layout of ``torch.optim.Adam(policy.parameters()).state_dict()`` -- what upstream's runner saves and loads
+        (``state`` by parameter index in ``policy.parameters()`` order: step, exp_avg, exp_avg_sq; one ``param_groups`` entry) --
+        plus ``imx_adam_state``: the 8 device-side scalars (lr, step, beta powers ...) for an exact resume here."""
+        base = self.bucket.flat.data_ptr()
+        state, params = {}, []
+        step = self._adam[1:2].clone().reshape(())
+        for i, p in enumerate(q for q in self.policy.parameters() if q.requires_grad):
             off = (p.data_ptr() - base) // 4
-            out["exp_avg"][name] = self.bucket.exp_avg[off:off + p.numel()].view_as(p).clone()
-            out["exp_avg_sq"][name] = self.bucket.exp_avg_sq[off:off + p.numel()].view_as(p).clone()
-        return out
+            params.append(i)
+            if float(step) > 0:
+                state[i] = {"step": step.clone(), "exp_avg": self.bucket.exp_avg[off:off + p.numel()].view_as(p).clone(),
+                            "exp_avg_sq": self.bucket.exp_avg_sq[off:off + p.numel()].view_as(p).clone()}
+        group = {"lr": self.learning_rate, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": params}
+        return {"state": state, "param_groups": [group], "imx_adam_state": self._adam.clone()}
 
     def load_optimizer_state_dict(self, o: dict) -> None:
+        """Accepts a torch Adam state dict (upstream checkpoints, and the ones written here) or the name-keyed layout of round 1."""
         base = self.bucket.flat.data_ptr()
+        if "state" in o and "param_groups" in o:
+            plist = [q for q in self.policy.parameters() if q.requires_grad]
+            if len(o["param_groups"]) != 1 or len(o["param_groups"][0]["params"]) != len(plist):
+                raise ValueError("optimizer state dict does not match the policy: "
+                                 f"{len(o['param_groups'][0]['params'])} parameters in the checkpoint, {len(plist)} here")
+            step = 0.0
+            self.bucket.exp_avg.zero_()
+            self.bucket.exp_avg_sq.zero_()
+            for i, p in enumerate(plist):
+                st = o["state"].get(i)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)} vs {tuple(p.shape)}")
+                off = (p.data_ptr() - base) // 4
+                self.bucket.exp_avg[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                self.bucket.exp_avg_sq[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                step = float(st["step"])
+            if "imx_adam_state" in o:
+                self._adam.copy_(o["imx_adam_state"])
+            else:  # an upstream checkpoint: rebuild the device scalars from lr / step / betas
+                g = o["param_groups"][0]
+                b1, b2 = g.get("betas", self.betas)
+                self._adam.copy_(torch.tensor([float(g["lr"]), step, b1 ** step, b2 ** step, 1.0, 0.0, 1.0, 0.0]))
+            return
         if isinstance(o["exp_avg"], dict):
             for name, p in self.policy.named_parameters():
                 if p.requires_grad and name in o["exp_avg"]:

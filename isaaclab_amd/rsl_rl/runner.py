@@ -9,7 +9,9 @@ Episode statistics stay on the device; nothing in the loop synchronises with the
 
 from __future__ import annotations
 
+import json
 import os
+import subprocess
 import time
 
 import torch
@@ -18,6 +20,34 @@ import torch.distributed as dist
 from .actor_critic import ActorCritic
 from .gemm_tuning import enable_recorded_gemm_tuning
 from .ppo import PPO
+
+
+class ScalarWriter:
+    """``add_scalar(tag, value, step)`` like the TensorBoard ``SummaryWriter`` upstream's runner logs through (tensorboard is not in
+    this image): one JSON line per scalar in ``<log_dir>/scalars.jsonl``, and the last value of every tag in ``.last``."""
+
+    def __init__(self, log_dir: str):
+        os.makedirs(log_dir, exist_ok=True)
+        self._f = open(os.path.join(log_dir, "scalars.jsonl"), "a")
+        self.last: dict = {}
+
+    def add_scalar(self, tag: str, value, step: int):
+        v = float(value)
+        self.last[tag] = v
+        self._f.write(json.dumps({"tag": tag, "value": v, "step": int(step)}) + "\n")
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+class _NoFusedInference:
+    ok = False
+
+    def refresh(self):
+        pass
 
 
 class OnPolicyRunner:
@@ -72,6 +102,10 @@ class OnPolicyRunner:
         self._log_accum = torch.zeros(n_log, device=self.device)
         self._log_steps = 0
         self._obs = obs
+        # upstream learn(): privileged_obs = extras["observations"].get(privileged_obs_type, obs)
+        self._privileged_obs = extras["observations"][self.privileged_obs_type] if self.privileged_obs_type is not None else obs
+        self.writer = None
+        self.git_status_repos: list[str] = []
         self._act_seed = int(train_cfg.get("seed", 42)) * 1000003 + self.gpu_global_rank
         self.collection_time = self.learn_time = 0.0
 
@@ -104,17 +138,21 @@ class OnPolicyRunner:
         from .vecenv_wrapper import RslRlVecEnvWrapper
 
         return (isinstance(self.env, RslRlVecEnvWrapper) and isinstance(self.env.unwrapped, ManagerBasedRLEnv)
-                and self.privileged_obs_type is None and self.alg.policy.noise_std_type == "scalar"
+                and self.alg.policy.noise_std_type == "scalar"
                 and self.device.type == "cuda" and not self.empirical_normalization)
 
     def _rollout(self):
         if self._fusable():
             return self._rollout_fused()
-        obs = self._obs
+        obs, privileged_obs = self._obs, self._privileged_obs
         for _ in range(self.num_steps_per_env):
-            actions = self.alg.act(obs, obs)
+            actions = self.alg.act(obs, privileged_obs)
             obs, rewards, dones, infos = self.env.step(actions)
             obs = self.obs_normalizer(obs)  # upstream: normalise right after env.step (the first obs stays raw)
+            if self.privileged_obs_type is not None:  # upstream on_policy_runner.py: the critic reads its own observation group
+                privileged_obs = self.privileged_obs_normalizer(infos["observations"][self.privileged_obs_type])
+            else:
+                privileged_obs = obs
             self.alg.process_env_step(rewards, dones, infos)
             # episode book-keeping on the device (upstream pulls finished episodes to the host every step)
             self._cur_reward_sum += rewards
@@ -125,6 +163,10 @@ class OnPolicyRunner:
             self._ep_stats[2] += done_f.sum()
             self._cur_reward_sum *= 1.0 - done_f
             self._cur_episode_length *= 1.0 - done_f
+            log_out = getattr(self.env.unwrapped, "_log_out", None)
+            if log_out is not None:  # ep_infos.append(infos["log"]) per step, kept as a running sum on the device
+                self._log_accum += log_out
+        self._privileged_obs = privileged_obs
         if self._graph_capturing:
             self._obs_out.copy_(obs)
         return obs
@@ -144,13 +186,16 @@ class OnPolicyRunner:
         step_ptr = env._counters[2:3].data_ptr()
         bootstrap = 0 if env.is_finite_horizon else 1
         obs = self._obs
+        priv = self.privileged_obs_type  # a "critic" observation group: the critic reads it, the storage keeps it
+        cobs = self._privileged_obs if priv is not None else obs
         if self._infer is not None:
             self._infer.refresh()  # the update changed the parameters: padded weight copies follow (inside the graph too)
         for t in range(self.num_steps_per_env):
             if self._infer is None:
                 from .ppo import FusedInference
 
-                self._infer = FusedInference(alg._actor_layers, alg._critic_layers)
+                # one launch for both networks needs a shared input; with a critic group the two stacks run side by side instead
+                self._infer = FusedInference(alg._actor_layers, alg._critic_layers) if priv is None else _NoFusedInference()
                 self._mu_buf = torch.empty(N, A, device=self.device)
                 self._value_buf = torch.empty(N, 1, device=self.device)
             if self._infer.ok:  # both networks, all layers, one launch (activations stay in LDS)
@@ -162,13 +207,15 @@ class OnPolicyRunner:
                     main = torch.cuda.current_stream(self.device)
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        value, _ = mlp_forward(alg._critic_layers, obs)
+                        value, _ = mlp_forward(alg._critic_layers, cobs)
                     mu, _ = mlp_forward(alg._actor_layers, obs)
                     main.wait_stream(side)
                     value.record_stream(main)
                 else:
                     mu, _ = mlp_forward(alg._actor_layers, obs)
-                    value, _ = mlp_forward(alg._critic_layers, obs)
+                    value, _ = mlp_forward(alg._critic_layers, cobs)
+            if priv is not None:
+                st.privileged_observations[t].copy_(cobs)
             check(L.imx_policy_act(N, A, D, mu.data_ptr(), pol.std.data_ptr(), value.data_ptr(), obs.data_ptr(),
                                    self._act_seed, step_ptr, st.actions[t].data_ptr(), st.actions_log_prob[t].data_ptr(),
                                    st.mu[t].data_ptr(), st.sigma[t].data_ptr(), st.values[t].data_ptr(),
@@ -180,9 +227,14 @@ class OnPolicyRunner:
                                      self._ep_stats.data_ptr(), env._log_out.data_ptr(), self._log_accum.data_ptr(),
                                      self._log_accum.numel(), stream))
             obs = obs_dict["policy"]
+            if priv is not None:
+                cobs = obs_dict[priv]
+        self._privileged_obs = cobs if priv is not None else obs
         st.step = self.num_steps_per_env
         if self._graph_capturing:
             self._obs_out.copy_(obs)
+            if priv is not None:
+                self._priv_out.copy_(cobs)
         return obs
 
     _graph_capturing = False
@@ -206,6 +258,10 @@ class OnPolicyRunner:
                 self._obs_in = self._obs.clone()
                 self._obs_out = torch.empty_like(self._obs)
                 self._obs = self._obs_in
+                if self.privileged_obs_type is not None:
+                    self._priv_in = self._privileged_obs.clone()
+                    self._priv_out = torch.empty_like(self._privileged_obs)
+                    self._privileged_obs = self._priv_in
                 self._graph = torch.cuda.CUDAGraph()
                 self._graph_capturing = True
                 feed_idx = self.env.unwrapped.feed.index
@@ -215,8 +271,12 @@ class OnPolicyRunner:
                 if self.env.unwrapped.feed.index != feed_idx:
                     raise RuntimeError("rollout graph needs num_steps_per_env to be a multiple of the feed's snapshot count")
                 self._obs = self._obs_in
+                if self.privileged_obs_type is not None:
+                    self._privileged_obs = self._priv_in
             else:
                 self._obs_in.copy_(self._obs_out)
+                if self.privileged_obs_type is not None:
+                    self._priv_in.copy_(self._priv_out)
             self._graph.replay()
             self.alg.storage.step = self.num_steps_per_env
             self.env.unwrapped.common_step_counter += self.num_steps_per_env
@@ -225,26 +285,99 @@ class OnPolicyRunner:
     def last_obs(self):
         return self._obs_out if self.use_graph else self._obs
 
+    @property
+    def last_critic_obs(self):
+        """What upstream hands to ``compute_returns``: the privileged observations after the last step (the policy observations
+        when the env has no privileged group)."""
+        if self.privileged_obs_type is None:
+            return self.last_obs
+        return self._priv_out if self.use_graph else self._privileged_obs
+
     def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False):
+        if self.log_dir is not None and self.writer is None and not self.disable_logs:
+            self.writer = ScalarWriter(self.log_dir)
+            self._store_code_state()
         if init_at_random_ep_len:
             self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
         self.train_mode()
         if self.is_distributed:
             self.alg.broadcast_parameters()
         start_iter = self.current_learning_iteration
-        for it in range(start_iter, start_iter + num_learning_iterations):
+        tot_iter = start_iter + num_learning_iterations
+        for it in range(start_iter, tot_iter):
             t0 = time.perf_counter()
             self.collect()
             with torch.inference_mode():
-                self.alg.compute_returns(self.last_obs)
+                self.alg.compute_returns(self.last_critic_obs)
+            if self.writer is not None:
+                torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None  # logging runs: honest phase times
             t1 = time.perf_counter()
             self.alg.update()
+            if self.writer is not None and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             t2 = time.perf_counter()
             self.collection_time, self.learn_time = t1 - t0, t2 - t1
             self.current_learning_iteration = it + 1
             self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * self.gpu_world_size
-            if self.log_dir is not None and not self.disable_logs and (it + 1) % self.save_interval == 0:
-                self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
+            self.tot_time += self.collection_time + self.learn_time
+            if self.writer is not None:
+                self.log(it, tot_iter)
+                if (it + 1) % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
+        if self.writer is not None:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+            self.writer.flush()
+
+    def log(self, it: int, tot_iter: int, width: int = 80, pad: int = 35):
+        """Upstream ``OnPolicyRunner.log``: the scalars IsaacLab's benchmark reads back (scripts/benchmarks/benchmark_rsl_rl.py:
+        220-231: ``Perf/total_fps``, ``Perf/collection time``, ``Perf/learning_time``, ``Train/mean_reward``,
+        ``Train/mean_episode_length``), the losses, and the per-iteration mean of the env's ``extras["log"]`` entries
+        (``Episode_Reward/<term>``, ``Episode_Termination/<term>``, envs/manager_based_rl_env.py:365-389).  ONE host read per
+        iteration (the sums live on the device; upstream pulls finished episodes every step).  Deviation: ``Train/mean_reward`` /
+        ``mean_episode_length`` average the episodes finished in THIS iteration (upstream: a window of the last 100 episodes)."""
+        env = self.env.unwrapped
+        collection_size = self.num_steps_per_env * self.env.num_envs * self.gpu_world_size
+        iteration_time = self.collection_time + self.learn_time
+        fps = int(collection_size / max(iteration_time, 1e-9))
+        w = self.writer
+        names = list(getattr(env, "_log_views", {}).keys())
+        acc = self._log_accum.tolist()
+        self._log_accum.zero_()
+        ep_string = ""
+        for i, key in enumerate(names):  # mean over the steps of the iteration of infos["log"][key]
+            value = acc[i] / self.num_steps_per_env
+            w.add_scalar(key if "/" in key else "Episode/" + key, value, it)
+            ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
+        loss = self.alg.loss_dict()
+        for key, value in loss.items():
+            w.add_scalar(f"Loss/{key}", value, it)
+        w.add_scalar("Loss/learning_rate", self.alg.learning_rate, it)
+        pol = self.alg.policy
+        std = pol.std if pol.noise_std_type == "scalar" else torch.exp(pol.log_std)
+        mean_std = float(std.detach().mean())
+        w.add_scalar("Policy/mean_noise_std", mean_std, it)
+        w.add_scalar("Perf/total_fps", fps, it)
+        w.add_scalar("Perf/collection time", self.collection_time, it)
+        w.add_scalar("Perf/learning_time", self.learn_time, it)
+        stats = self.episode_stats()
+        self._ep_stats.zero_()
+        if stats["episodes"] > 0:
+            self._last_train = (stats["mean_reward"], stats["mean_episode_length"])
+        if getattr(self, "_last_train", None) is not None:
+            w.add_scalar("Train/mean_reward", self._last_train[0], it)
+            w.add_scalar("Train/mean_episode_length", self._last_train[1], it)
+            w.add_scalar("Train/mean_reward/time", self._last_train[0], int(self.tot_time))
+            w.add_scalar("Train/mean_episode_length/time", self._last_train[1], int(self.tot_time))
+        title = f" Learning iteration {it}/{tot_iter} "
+        lines = [f"""{'#' * width}""", f"""{title.center(width, ' ')}""", "",
+                 f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {self.collection_time:.3f}s, learning {self.learn_time:.3f}s)""",
+                 f"""{'Mean action noise std:':>{pad}} {mean_std:.2f}"""]
+        lines += [f"""{f'Mean {k} loss:':>{pad}} {v:.4f}""" for k, v in loss.items()]
+        if getattr(self, "_last_train", None) is not None:
+            lines += [f"""{'Mean reward:':>{pad}} {self._last_train[0]:.2f}""", f"""{'Mean episode length:':>{pad}} {self._last_train[1]:.2f}"""]
+        self.last_log_string = "\n".join(lines) + "\n" + ep_string
+        if os.getenv("IMX_RUNNER_QUIET") != "1":
+            print(self.last_log_string)
 
     def episode_stats(self) -> dict:
         s = self._ep_stats.tolist()
@@ -253,16 +386,32 @@ class OnPolicyRunner:
 
     # ---- checkpoint / inference (train.py / play.py surface) ---------------------------------------------------
     def save(self, path: str, infos=None):
+        """Upstream checkpoint layout: ``model_state_dict``, ``optimizer_state_dict`` (a torch.optim.Adam state dict), ``iter``,
+        ``infos`` and, with empirical normalisation, ``obs_norm_state_dict`` / ``privileged_obs_norm_state_dict``."""
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        torch.save({"model_state_dict": self.alg.policy.state_dict(),
-                    "optimizer_state_dict": self.alg.optimizer_state_dict(),
-                    "iter": self.current_learning_iteration, "infos": infos}, path)
+        d = {"model_state_dict": self.alg.policy.state_dict(), "optimizer_state_dict": self.alg.optimizer_state_dict(),
+             "iter": self.current_learning_iteration, "infos": infos}
+        if self.empirical_normalization:
+            d["obs_norm_state_dict"] = self.obs_normalizer.state_dict()
+            d["privileged_obs_norm_state_dict"] = self.privileged_obs_normalizer.state_dict()
+        torch.save(d, path)
 
     def load(self, path: str, load_optimizer: bool = True):
         d = torch.load(path, weights_only=True, map_location=self.device)
         with torch.no_grad():
+            own = self.alg.policy.state_dict()
+            missing = [k for k in own if k not in d["model_state_dict"]]
+            if missing:
+                raise KeyError(f"checkpoint lacks policy parameters {missing}")
             for k, v in d["model_state_dict"].items():
-                self.alg.policy.state_dict()[k].copy_(v)  # in place: parameters stay views of the flat bucket
+                if k in own:
+                    own[k].copy_(v)  # in place: parameters stay views of the flat bucket
+        if self.empirical_normalization:
+            if "obs_norm_state_dict" not in d:
+                raise KeyError("the runner normalises observations (empirical_normalization=True) but the checkpoint carries no "
+                               "obs_norm_state_dict: its policy was trained on raw observations")
+            self.obs_normalizer.load_state_dict(d["obs_norm_state_dict"])
+            self.privileged_obs_normalizer.load_state_dict(d["privileged_obs_norm_state_dict"])
         if load_optimizer and "optimizer_state_dict" in d:
             self.alg.load_optimizer_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d.get("iter", 0)
@@ -272,7 +421,13 @@ class OnPolicyRunner:
         self.eval_mode()
         if device is not None:
             self.alg.policy.to(device)
-        return self.alg.policy.act_inference
+        policy = self.alg.policy.act_inference
+        if self.empirical_normalization:  # upstream: policy = lambda x: act_inference(obs_normalizer(x))
+            if device is not None:
+                self.obs_normalizer.to(device)
+            norm, act = self.obs_normalizer, self.alg.policy.act_inference
+            policy = lambda x: act(norm(x))  # noqa: E731
+        return policy
 
     def train_mode(self):
         self.alg.policy.train()
@@ -287,4 +442,22 @@ class OnPolicyRunner:
             self.privileged_obs_normalizer.eval()
 
     def add_git_repo_to_log(self, repo_file_path):
-        pass
+        self.git_status_repos.append(repo_file_path)
+
+    def _store_code_state(self):
+        """Upstream ``store_code_state``: ``git status`` / ``git diff`` of every registered repository next to the logs."""
+        for path in self.git_status_repos:
+            root = path if os.path.isdir(path) else os.path.dirname(path)
+            try:
+                top = subprocess.run(["git", "-C", root, "rev-parse", "--show-toplevel"], capture_output=True, text=True, timeout=20)
+                if top.returncode != 0:
+                    continue
+                top_dir = top.stdout.strip()
+                out = os.path.join(self.log_dir, "git")
+                os.makedirs(out, exist_ok=True)
+                name = os.path.basename(top_dir) or "repo"
+                with open(os.path.join(out, f"{name}.diff"), "w") as f:
+                    f.write("--- git status ---\n" + subprocess.run(["git", "-C", top_dir, "status"], capture_output=True, text=True, timeout=20).stdout)
+                    f.write("\n\n--- git diff ---\n" + subprocess.run(["git", "-C", top_dir, "diff"], capture_output=True, text=True, timeout=20).stdout)
+            except (OSError, subprocess.SubprocessError):
+                continue

@@ -1,7 +1,10 @@
 """``RslRlVecEnvWrapper`` with the reference's surface (isaaclab_rl/rsl_rl/vecenv_wrapper.py:14-209).
 
 Differences that matter for speed, none for results: the action clamp (``:173-174``) is fused into
-``imx_action_process``; ``dones`` is produced without touching the host.
+``imx_action_process``; ``dones`` is produced without touching the host.  The env writes its observation groups into
+persistent buffers (fixed pointers: hipGraph capture); the reference's ObservationManager returns NEW tensors every step and
+RSL-RL keeps references to them across ``env.step`` (``transition.observations = obs``), so this wrapper hands out copies.
+The fused rollout of ``OnPolicyRunner`` talks to the env directly and never pays for them.
 """
 
 from __future__ import annotations
@@ -53,7 +56,7 @@ class RslRlVecEnvWrapper:
         return self.env.unwrapped
 
     def get_observations(self) -> tuple[torch.Tensor, dict]:
-        obs_dict = self.unwrapped.observation_manager.compute()
+        obs_dict = {k: v.clone() for k, v in self.unwrapped.observation_manager.compute().items()}
         return obs_dict["policy"], {"observations": obs_dict}
 
     @property
@@ -69,12 +72,14 @@ class RslRlVecEnvWrapper:
 
     def reset(self) -> tuple[torch.Tensor, dict]:
         obs_dict, _ = self.env.reset()
+        obs_dict = {k: v.clone() for k, v in obs_dict.items()}
         return obs_dict["policy"], {"observations": obs_dict}
 
     def step(self, actions: torch.Tensor):
         # the clamp of vecenv_wrapper.py:173-174 happens inside imx_action_process (env.clip_actions)
         obs_dict, rew, terminated, truncated, extras = self.env.step(actions)
         dones = (terminated | truncated).to(dtype=torch.long)
+        obs_dict = {k: v.clone() for k, v in obs_dict.items()}
         obs = obs_dict["policy"]
         extras["observations"] = obs_dict
         if not self.unwrapped.is_finite_horizon:
