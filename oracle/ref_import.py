@@ -5,7 +5,7 @@ import time.  None of those exist here, so this module installs a ``sys.meta_pat
 modules for the missing roots, a tiny real ``gymnasium`` (``Env``/``Wrapper``/``register``) and a ``toml`` shim over
 ``tomli``; then it puts the reference's source roots on ``sys.path``.  Nothing is written to ``/root/reference``
 (``sys.dont_write_bytecode``).  This is used ONLY by ``oracle/gen_golden.py`` to produce the committed fixtures under
-``tests/golden`` and by ``oracle/time_reference.py``; it never travels to the GPU box as a dependency of anything
+``tests/golden`` and by ``oracle/time_reference.py`` (reference vs restatement timing); it never travels to the GPU box as a dependency of anything
 (the reference itself does not exist there).
 """
 
