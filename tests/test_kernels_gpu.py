@@ -67,11 +67,31 @@ def test_raycast_matches_brute_force_oracles():
     d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
     mesh = TerrainMesh(v, t, 0.1)
     hits, dist, _, face = mesh.raycast(torch.from_numpy(s2).cuda(), torch.from_numpy(d2).cuda(), 50.0, True, True)
+    dist, face = dist.cpu().numpy(), face.cpu().numpy()
+    # (1) against the brute force in the SAME fp32 Woop arithmetic: the grid walk must find exactly the triangle the exhaustive search
+    #     finds -- every disagreement is enumerated, none is tolerated
+    h32, t32, f32 = raycast_woop_f32(v, t, s2, d2, 50.0)
+    disagree = np.flatnonzero((np.isfinite(dist) != np.isfinite(t32)) | (np.isfinite(t32) & (dist != t32)))
+    assert disagree.size == 0, [(int(i), float(dist[i]), float(t32[i]), int(face[i]), int(f32[i])) for i in disagree[:10]]
+    assert np.isfinite(t32).mean() > 0.3  # shallow rays leave the small mesh; 1400+ hits
+    # (2) against the fp64 geometric truth: fp32 edge functions lose the hit point along the surface by ~eps * |coordinates|, which a ray
+    #     meeting the surface at grazing angle turns into eps * |coordinates| / cos(incidence) along the ray.  The 1e-5 contract of the
+    #     height scanner (vertical rays on a terrain) is met by every ray that is not grazing; for the others the bound scales with
+    #     1 / cos, and hit / miss may flip only for rays that pass an edge or the max_dist sphere within that distance.
     h64, t64, f64 = raycast_f64(v, t, s2, d2, 50.0)
-    dist = dist.cpu().numpy()
     both = np.isfinite(dist) & np.isfinite(t64)
-    assert (np.isfinite(dist) != np.isfinite(t64)).mean() < 2e-3  # grazing rays at max_dist / silhouette edges
-    assert np.abs(dist[both] - t64[both]).max() <= 1e-3 and np.median(np.abs(dist[both] - t64[both])) <= 1e-5
+    tri = v[t[f64[both]]]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    cosi = np.abs((n * d2[both]).sum(1)) / np.maximum(np.linalg.norm(n, axis=1), 1e-30)
+    err = np.abs(dist[both] - t64[both])
+    steep = cosi > 0.2
+    rel = err / np.maximum(t64[both], 1.0)
+    print("DDA vs fp64: steep rays %d, max rel err steep %.2e, max err*cos %.2e, hit/miss flips %d" % (
+        int(steep.sum()), float(rel[steep].max()), float((err * cosi).max()), int((np.isfinite(dist) != np.isfinite(t64)).sum())))
+    assert steep.mean() > 0.5 and rel[steep].max() <= 1e-5
+    assert (err * np.maximum(cosi, 1e-3)).max() <= 1e-5  # measured 1.4e-6: the along-ray error is <= 1e-5 / cos(incidence)
+    flips = np.flatnonzero(np.isfinite(dist) != np.isfinite(t64))
+    assert flips.size == 0, [(int(i), float(dist[i]), float(t64[i])) for i in flips]  # no hit / miss disagreement with the fp64 truth
     # empty input
     e = torch.empty(0, 3, device="cuda")
     assert mesh.raycast(e, e)[0].shape == (0, 3)
