@@ -71,34 +71,29 @@ struct PlanView {
 PlanView imx_plan_view(const imx_plan* p);
 
 // ---- mesh ---------------------------------------------------------------------------------------------------------
-// Cells of the xy grid are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height scanner maps
-// to a handful of contiguous runs.  One 16-byte descriptor per cell {meta, id0, id1, zrest}; meta:
-//   kind = desc & 3:  0 empty
-//                     1 LATTICE  the cell holds exactly the two triangles (a,b,c),(a,d,b) of one height-field quad
-//                                (convert_height_field_to_mesh topology); face ids = desc>>2 and +1; its corners sit in
-//                                the tile's 9x9 vertex pool: slot (py*9+px) = a, +1 = d, +9 = c, +10 = b.  A vertex is
-//                                stored once per tile and shared by the up to four cells around it (16 B / vertex).
-//                     2 GENERAL  count = (desc>>2)&63 (even) references starting at refs[desc>>8]; a reference is
-//                                {triangle id, zrest}: sorted by descending triangle top (max z), zrest = highest top
-//                                among the references after it (a downward ray stops once its hit is above zrest).
-//                                The first pair (id0, id1, zrest after it) is repeated in the descriptor, so an
-//                                interior cell of a box top needs descriptor -> two records and nothing else.
-//                                Triangle records (48 B, ONE per triangle, shared by all the cells that reference it --
-//                                a box face covering hundreds of cells stays hot in L2):
-//                                ax ay az bx | by bz cx cy | cz face(int) ztop 0
-//                     3 GENERAL_IND  the same through gtab[desc>>2] = {first record, count} (first >= 2^24 or count > 63)
-//                     FLAT (a GENERAL / GENERAL_IND cell with bit 31 of id0 set): the highest surface over the cell's interior is
-//                                horizontal at height w (which then replaces zrest): a downward vertical ray that is not within tau
-//                                of a cell boundary hits z = w -- the descriptor answers it, no record is loaded (mesh.hip).
+// Cells of the xy grid are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height scanner maps to a handful
+// of contiguous runs.  32 bytes per cell: a = four floats, b = {kind, ...} (mesh.hip pass 2 says what qualifies):
+//   kind 0 EMPTY
+//        1 LATTICE  the two triangles (a,b,c),(a,d,b) of one height-field quad (convert_height_field_to_mesh topology) with corners
+//                   on the grid's coordinate lines gx[ix], gx[ix+1], gy[iy], gy[iy+1]: a = heights of a (ix,iy), d (ix+1,iy),
+//                   c (ix,iy+1), b (ix+1,iy+1); b.y = face id of (a,b,c), the other triangle is b.y + 1
+//        2 QH       the highest surface over the cell's interior is horizontal in each of the <= 4 rectangles the lines x = cx,
+//                   y = cy cut it into: a = {h00 (x<cx,y<cy), h10, h01, h11}; b = {kind, cx, cy, a face id} (+inf = no line)
+//        3 GENERAL  a = {-, id0, id1, zrest after the first pair}; b = {kind, first reference, count (even)}
+//   QH and GENERAL cells also have cell_list[c] = {first reference, count}: a reference is {triangle id, zrest}, sorted by descending
+//   triangle top (max z), zrest = highest top among the references after it (a downward ray stops once its hit is above zrest);
+//   refs holds them as pairs {id0, zrest0, id1, zrest1}.  Triangle records (48 B, ONE per triangle, shared by all the cells that
+//   reference it -- a box face covering hundreds of cells stays hot in L2): ax ay az bx | by bz cx cy | cz face(int) ztop 0
 #define IMX_CELL_EMPTY 0
 #define IMX_CELL_LATTICE 1
-#define IMX_CELL_GENERAL 2
-#define IMX_CELL_GENERAL_IND 3
+#define IMX_CELL_QH 2
+#define IMX_CELL_GENERAL 3
 struct MeshView {
-    const int4* cell_desc;     // (ntx*nty*64) {meta, id0, id1, zrest after the first pair}
-    const float4* tile_pool;   // (ntx*nty*81) xyz0
-    const int2* gtab;          // (general cells with out-of-range inline fields)
-    const int4* refs;          // (general references / 2) pairs {id0, zrest0, id1, zrest1}
+    const int4* cells;         // (ntx*nty*64 x 2) {a, b} per cell
+    const int2* cell_list;     // (ntx*nty*64) {first reference, count} of the QH / GENERAL cells
+    const float* gx;           // (nx+1) lattice coordinate lines
+    const float* gy;           // (ny+1)
+    const int4* refs;          // (references / 2) pairs {id0, zrest0, id1, zrest1}
     const float4* tri_rec;     // (F, 3 x float4)
     int ntx, nty;
     int nx, ny;
@@ -107,14 +102,15 @@ struct MeshView {
 };
 struct imx_mesh {
     MeshView v{};
-    int32_t* d_cell_desc = nullptr;
-    float* d_tile_pool = nullptr;
-    int32_t* d_gtab = nullptr;
+    int32_t* d_cell = nullptr;
+    int32_t* d_cell_list = nullptr;
+    float* d_gx = nullptr;
+    float* d_gy = nullptr;
     float* d_tri_rec = nullptr;
     int32_t* d_refs = nullptr;
     int64_t num_refs = 0;  // general cell references
     int32_t max_refs = 0;
-    int64_t n_lattice = 0, n_general = 0, n_flat = 0;
+    int64_t n_lattice = 0, n_general = 0, n_flat = 0;  // n_general counts QH (n_flat) and GENERAL cells
 };
 // linear index of cell (ix, iy) in the 8x8-tiled layout
 static __host__ __device__ __forceinline__ int imx_cell_index(int ix, int iy, int ntx) {

@@ -9,7 +9,11 @@
 // functions with the fp64 fallback on exact zeros, two-sided, t >= 0.  Same arithmetic as
 // oracle/raycast_oracle.c:woop_f32 (compile with -ffp-contract=off on both sides).
 //
-// Grid membership (host builder in mesh.cpp): with g = (coord - origin) * inv_cell, a triangle spanning
+// A vertical ray on a height-field quad (LATTICE cell) or over horizontal faces (QH cell) is answered from the cell's own 32 bytes:
+// see vertical_cell below and imx_internal.h.  The Woop test remains for everything else (GENERAL cells, rays on cell boundaries,
+// slanted rays).
+//
+// Grid membership (host builder in mesh.hip): with g = (coord - origin) * inv_cell, a triangle spanning
 // [g_lo, g_hi] is listed in cells floor(g_lo + tau) .. ceil(g_hi - tau) - 1 (at least one cell), tau = IMX_GRID_TAU.
 // A ray at g_r looks at floor(g_r), plus the lower neighbour when frac(g_r) < tau and the upper neighbour when
 // frac(g_r) > 1 - tau.  Every triangle whose xy-extent contains the ray is therefore seen, and a height-field
@@ -100,17 +104,17 @@ IMX_DEV void test_tri(const WoopRay& r, float4 a, float4 b, float4 c, int32_t f,
 IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int32_t d = m.cell_desc[c].x;
-    const int kind = d & 3;
-    if (kind == IMX_CELL_LATTICE) {
-        const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
-        const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
-        const int32_t f0 = (int32_t)((uint32_t)d >> 2);
-        test_tri(r, va, vb, vc, f0, best, face);      // (a, b, c)
-        test_tri(r, va, vd, vb, f0 + 1, best, face);  // (a, d, b)
-    } else if (kind != IMX_CELL_EMPTY) {  // (the FLAT mark of a descriptor lives in its id0 word, which this path does not read)
-        int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
-        if (kind == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
+    const int4 b4 = m.cells[2 * (size_t)c + 1];
+    const int kind = b4.x;
+    if (kind == IMX_CELL_LATTICE) {  // the quad's corners: grid lines x heights
+        const int4 a4 = m.cells[2 * (size_t)c];
+        const float x0 = m.gx[ix], x1 = m.gx[ix + 1], y0 = m.gy[iy], y1 = m.gy[iy + 1];
+        const float4 va = make_float4(x0, y0, __int_as_float(a4.x), 0.0f), vd = make_float4(x1, y0, __int_as_float(a4.y), 0.0f);
+        const float4 vc = make_float4(x0, y1, __int_as_float(a4.z), 0.0f), vb = make_float4(x1, y1, __int_as_float(a4.w), 0.0f);
+        test_tri(r, va, vb, vc, b4.y, best, face);      // (a, b, c)
+        test_tri(r, va, vd, vb, b4.y + 1, best, face);  // (a, d, b)
+    } else if (kind != IMX_CELL_EMPTY) {  // QH / GENERAL: the full reference list
+        const int2 g = m.cell_list[c];
         for (int k = g.x; k < g.x + g.y; k += 2) {
             const int4 rr = m.refs[k >> 1];
             const float4* q0 = m.tri_rec + (size_t)rr.x * 3;
@@ -166,13 +170,11 @@ IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_,
     }
 }
 
-// the references of a GENERAL / GENERAL_IND cell after its first pair (which the descriptor itself carries)
-IMX_DEV void vertical_cell_tail(const MeshView& m, int32_t d, float ox, float oy, float oz, bool flip, float Sz, float dz,
-                                float& best, int32_t& face) {
-    int2 g = make_int2((int)((uint32_t)d >> 8), (int)(((uint32_t)d >> 2) & 63u));
-    if ((d & 3) == IMX_CELL_GENERAL_IND) g = m.gtab[(uint32_t)d >> 2];
-    const int end = g.x + g.y;
-    for (int k = g.x + 2; k < end; k += 2) {  // the rest of the list: one 16-byte load gives the next two ids
+// references [k0, end) of a cell's list, two per trip (one 16-byte load gives the next two ids); a downward ray stops once its hit
+// lies above everything that is left
+IMX_DEV void vertical_list(const MeshView& m, int k0, int end, float ox, float oy, float oz, bool flip, float Sz, float dz,
+                           float& best, int32_t& face) {
+    for (int k = k0; k < end; k += 2) {
         const int4 rr = m.refs[k >> 1];
         const float4* p = m.tri_rec + (size_t)rr.x * 3;
         const float4* p2 = m.tri_rec + (size_t)rr.z * 3;
@@ -186,44 +188,63 @@ IMX_DEV void vertical_cell_tail(const MeshView& m, int32_t d, float ox, float oy
     }
 }
 
+IMX_DEV void take_hit(float t, int32_t f, float& best, int32_t& face) {
+    if (t >= 0.0f && (t < best || (face < 0 && t <= best))) {
+        best = t;
+        face = f;
+    }
+}
+
+// One cell, vertical ray.  `interior`: the ray is not within tau of a cell boundary (then a QH cell answers from its heights).
 IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
                            bool interior, float& best, int32_t& face) {
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    int4 d4 = m.cell_desc[c];
-    const int32_t d = d4.x;
-    const int kind = d & 3;
-    if (d4.y < 0) {  // FLAT cell (see imx_internal.h): the descriptor answers an interior downward ray
-        d4.y &= 0x7FFFFFFF;
+    const int4 a4 = m.cells[2 * (size_t)c];  // both halves of the cell and (lattice) its four grid lines: one load level
+    const int4 b4 = m.cells[2 * (size_t)c + 1];
+    const int kind = b4.x;
+    if (kind == IMX_CELL_LATTICE) {
+        // Height-field quad a (x0,y0), d (x1,y0), c (x0,y1), b (x1,y1), split along a-b.  The ray is inside the quad or not by exact
+        // comparisons with its coordinate lines (neighbouring quads share them: no gaps, a ray ON a line is in both and gets the
+        // same height from either); the hit height is the plane of the triangle on its side of the diagonal, evaluated in the
+        // quad's own coordinates u, w in [0, 1] -- no 20 m lever arm between ray origin and surface as in the edge-function form.
+        const float x0 = m.gx[ix], x1 = m.gx[ix + 1], y0 = m.gy[iy], y1 = m.gy[iy + 1];
+        if (ox >= x0 && ox <= x1 && oy >= y0 && oy <= y1) {
+            const float za = __int_as_float(a4.x), zd = __int_as_float(a4.y), zc = __int_as_float(a4.z), zb = __int_as_float(a4.w);
+            const float u = (ox - x0) / (x1 - x0), w = (oy - y0) / (y1 - y0);
+            const bool upper = w >= u;  // the (a, b, c) side of the diagonal
+            const float z = upper ? za + ((zb - zc) * u + (zc - za) * w) : za + ((zd - za) * u + (zb - zd) * w);
+            take_hit(Sz * (z - oz), b4.y + (upper ? 0 : 1), best, face);
+        }
+    } else if (kind == IMX_CELL_QH) {
         if (interior && flip) {
-            const float t = Sz * (__int_as_float(d4.w) - oz);
-            if (t >= 0.0f && (t < best || (face < 0 && t <= best))) { best = t; face = d4.y; }
-            return;
+            // the highest surface is horizontal on either side of the lines x = cx, y = cy; a ray exactly on a line touches both sides
+            // and the closest hit is the higher one
+            const float cx = __int_as_float(b4.y), cy = __int_as_float(b4.z);
+            const float h00 = __int_as_float(a4.x), h10 = __int_as_float(a4.y), h01 = __int_as_float(a4.z), h11 = __int_as_float(a4.w);
+            const float lo = oy < cy ? (ox < cx ? h00 : (ox > cx ? h10 : fmaxf(h00, h10))) : -__builtin_huge_valf();
+            const float hi = oy > cy ? (ox < cx ? h01 : (ox > cx ? h11 : fmaxf(h01, h11))) : -__builtin_huge_valf();
+            const float on = oy == cy ? fmaxf(ox <= cx ? fmaxf(h00, h01) : -__builtin_huge_valf(), ox >= cx ? fmaxf(h10, h11) : -__builtin_huge_valf())
+                                      : -__builtin_huge_valf();
+            take_hit(Sz * (fmaxf(fmaxf(lo, hi), on) - oz), b4.w, best, face);
+        } else {  // a ray on a cell boundary, or an upward one: the full list
+            const int2 g = m.cell_list[c];
+            vertical_list(m, g.x, g.x + g.y, ox, oy, oz, flip, Sz, dz, best, face);
         }
-        d4.w = __float_as_int(__builtin_huge_valf());  // w held the height, not zrest: no early exit on the first pair
-    }
-    if (kind == IMX_CELL_LATTICE) {  // height-field quad: descriptor -> 4 shared corners of the tile's vertex pool
-        const float4* p = m.tile_pool + (size_t)(c >> 6) * 81 + ((iy & 7) * 9 + (ix & 7));
-        const float4 va = p[0], vd = p[1], vc = p[9], vb = p[10];
-        const int32_t f0 = (int32_t)((uint32_t)d >> 2);
-        vertical_tri(va.x, va.y, va.z, vb.x, vb.y, vb.z, vc.x, vc.y, vc.z, f0, ox, oy, oz, flip, Sz, best, face);
-        vertical_tri(va.x, va.y, va.z, vd.x, vd.y, vd.z, vb.x, vb.y, vb.z, f0 + 1, ox, oy, oz, flip, Sz, best, face);
-    } else if (kind != IMX_CELL_EMPTY) {
-        // first pair straight from the descriptor: descriptor -> two shared triangle records (six 16-byte loads)
-        {
-            const float4* p = m.tri_rec + (size_t)d4.y * 3;
-            const float4* p2 = m.tri_rec + (size_t)d4.z * 3;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
-            vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
-                         best, face);
-            vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
-                         best, face);
-            // references are sorted by descending top; d4.w = highest top among those after this pair.  A downward
-            // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
-            if (flip && face >= 0 && __int_as_float(d4.w) < oz + best * dz) return;
-        }
-        vertical_cell_tail(m, d, ox, oy, oz, flip, Sz, dz, best, face);
+    } else if (kind == IMX_CELL_GENERAL) {
+        // first pair straight from the cell: two shared triangle records (six 16-byte loads)
+        const float4* p = m.tri_rec + (size_t)a4.y * 3;
+        const float4* p2 = m.tri_rec + (size_t)a4.z * 3;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
+        vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
+                     best, face);
+        vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
+                     best, face);
+        // references are sorted by descending top; a4.w = highest top among those after this pair.  A downward
+        // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
+        if (flip && face >= 0 && __int_as_float(a4.w) < oz + best * dz) return;
+        vertical_list(m, b4.y + 2, b4.y + b4.z, ox, oy, oz, flip, Sz, dz, best, face);
     }
 }
 

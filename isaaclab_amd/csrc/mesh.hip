@@ -154,15 +154,22 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                     if (overlaps(f, ix, iy)) refs[cursor[(size_t)imx_cell_index(ix, iy, ntx)]++] = (int32_t)f;
     }
 
-    // ---- pass 2: encode every cell.  LATTICE cells (the two triangles of one height-field quad,
-    // (a,b,c) + (a,d,b) with consecutive ids, each referenced by this cell only) keep just a descriptor: their four
-    // corners live once in the tile's 9x9 vertex pool, shared with the neighbouring cells.  Everything else becomes a
-    // GENERAL cell: gtab entry {first record, count} + one 48-byte record per reference.
-    std::vector<int32_t> desc((size_t)ncell * 4, 0);  // int4 per cell: meta, id0, id1, zrest after the first pair
-    std::vector<float> pool((size_t)ntile * 81 * 4, 0.0f);
-    std::vector<uint8_t> pool_set((size_t)ntile * 81, 0);
-    std::vector<int32_t> gtab;
-    std::vector<int32_t> refl;  // (triangle id, zrest bits) pairs of the general cells
+    // ---- pass 2: encode every cell: 32 bytes {a: four floats, b: kind + three words} (imx_internal.h), so that ONE load level answers
+    // a vertical ray on almost every cell:
+    //   LATTICE  the two triangles (a,b,c) + (a,d,b) of one height-field quad whose corners sit on the grid's coordinate lines
+    //            gx[ix], gx[ix+1], gy[iy], gy[iy+1] (exact float compare; the lines are taken from the mesh itself, they are the
+    //            vertex coordinates of the height field): a = the four corner heights;
+    //   QH       ("quad heights") the highest surface over the cell's interior is horizontal in each of the <= 4 rectangles an
+    //            axis-aligned line x = cx and / or y = cy cuts the cell into -- box tops, stair treads, platforms, their edges and
+    //            corners, the plateaus of a snapped height field: a = the four heights, b = {kind, cx, cy, a face id};
+    //   GENERAL  everything else: a = {-, id0, id1, zrest} (first reference pair inline), b = {kind, first reference, count}.
+    // QH and GENERAL cells also keep their full reference list (cell_list -> refs -> 48-byte triangle records, one record per
+    // TRIANGLE shared by all cells): slanted rays, upward rays and rays within tau of a cell boundary walk it.
+    std::vector<int32_t> cellv((size_t)ncell * 8, 0);
+    std::vector<int32_t> clist((size_t)ncell * 2, 0);
+    const float qnan = std::nanf("");
+    std::vector<float> gxl((size_t)nx + 1, qnan), gyl((size_t)ny + 1, qnan);
+    std::vector<int32_t> refl;  // (triangle id, zrest bits) pairs of the non-lattice cells
     std::map<std::vector<int32_t>, uint64_t> dedup;  // reference list -> first index (identical lists are shared)
     // one 48-byte record per TRIANGLE (shared by every cell that references it): ax ay az bx | by bz cx cy | cz face ztop 0
     std::vector<float> recs((size_t)F * 12, 0.0f);
@@ -184,137 +191,171 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     auto single_cell = [&](int32_t f) {
         return ra[(size_t)f * 4] == ra[(size_t)f * 4 + 1] && ra[(size_t)f * 4 + 2] == ra[(size_t)f * 4 + 3];
     };
+    auto grid_x = [&](float x) { return ((double)x - (double)xmin) * (double)inv_cell; };
+    auto grid_y = [&](float y) { return ((double)y - (double)ymin) * (double)inv_cell; };
+    // a coordinate line of the lattice: the value the mesh uses for grid line i (first come, must lie on the line within 1 % of a cell)
+    auto claim = [&](std::vector<float>& line, int i, float v, double g) -> bool {
+        if (std::fabs(g - (double)i) > 0.01) return false;
+        if (std::isnan(line[i])) { line[i] = v; return true; }
+        return line[i] == v;
+    };
     for (int iy = 0; iy < (int)ny; ++iy)
         for (int ix = 0; ix < (int)nx; ++ix) {
             const int c = imx_cell_index(ix, iy, ntx);
             const int n = start[c + 1] - start[c];
             if (n == 0) continue;
             const int32_t* r = &refs[start[c]];
-            bool lattice = false;
+            int32_t* ca = &cellv[(size_t)c * 8];
+            int32_t* cb = ca + 4;
             if (n == 2 && r[1] == r[0] + 1 && single_cell(r[0]) && single_cell(r[1])) {
                 const uint32_t* t0 = tris + 3 * (size_t)r[0];
                 const uint32_t* t1 = tris + 3 * (size_t)r[1];
                 if (t0[0] == t1[0] && t0[1] == t1[2]) {  // (a,b,c), (a,d,b)
-                    const int64_t tile = c >> 6;
-                    const int px = ix & 7, py = iy & 7;
-                    const uint32_t corner_v[4] = {t0[0], t1[1], t0[2], t0[1]};  // a->(0,0) d->(1,0) c->(0,1) b->(1,1)
-                    const int slot[4] = {py * 9 + px, py * 9 + px + 1, (py + 1) * 9 + px, (py + 1) * 9 + px + 1};
-                    bool ok = true;
-                    for (int k = 0; k < 4 && ok; ++k) {
-                        const size_t s = (size_t)tile * 81 + slot[k];
-                        if (pool_set[s]) ok = memcmp(&pool[s * 4], verts + 3 * (size_t)corner_v[k], 12) == 0;
-                    }
-                    if (ok) {
-                        for (int k = 0; k < 4; ++k) {
-                            const size_t s = (size_t)tile * 81 + slot[k];
-                            memcpy(&pool[s * 4], verts + 3 * (size_t)corner_v[k], 12);
-                            pool_set[s] = 1;
-                        }
-                        desc[(size_t)c * 4] = (int32_t)(((uint32_t)r[0] << 2) | IMX_CELL_LATTICE);
-                        lattice = true;
+                    const float* va = verts + 3 * (size_t)t0[0];
+                    const float* vb = verts + 3 * (size_t)t0[1];
+                    const float* vc = verts + 3 * (size_t)t0[2];
+                    const float* vd = verts + 3 * (size_t)t1[1];
+                    // a -> (ix, iy), d -> (ix+1, iy), c -> (ix, iy+1), b -> (ix+1, iy+1): an axis-aligned rectangle on the grid lines
+                    const bool rect = va[0] == vc[0] && vd[0] == vb[0] && va[1] == vd[1] && vc[1] == vb[1] && va[0] < vd[0] && va[1] < vc[1];
+                    // (claims are only made when all four would hold, so a rejected quad leaves no line behind)
+                    auto would = [&](const std::vector<float>& line, int i, float v, double g) {
+                        return std::fabs(g - (double)i) <= 0.01 && (std::isnan(line[i]) || line[i] == v);
+                    };
+                    if (rect && would(gxl, ix, va[0], grid_x(va[0])) && would(gxl, ix + 1, vd[0], grid_x(vd[0])) &&
+                        would(gyl, iy, va[1], grid_y(va[1])) && would(gyl, iy + 1, vc[1], grid_y(vc[1]))) {
+                        claim(gxl, ix, va[0], grid_x(va[0])); claim(gxl, ix + 1, vd[0], grid_x(vd[0]));
+                        claim(gyl, iy, va[1], grid_y(va[1])); claim(gyl, iy + 1, vc[1], grid_y(vc[1]));
+                        memcpy(&ca[0], &va[2], 4); memcpy(&ca[1], &vd[2], 4); memcpy(&ca[2], &vc[2], 4); memcpy(&ca[3], &vb[2], 4);
+                        cb[0] = IMX_CELL_LATTICE;
+                        cb[1] = r[0];
                         ++n_lattice;
+                        continue;
                     }
                 }
             }
-            if (!lattice) {
-                // references sorted by descending top (max z), ties by triangle id; each carries zrest = the highest top
-                // among the references AFTER it, so a downward ray stops as soon as its hit lies above what is left
-                const int npad = (n + 1) & ~1;
-                std::vector<std::pair<float, int32_t>> order((size_t)n);
-                for (int k = 0; k < n; ++k) order[k] = {ztop[(size_t)r[k]], r[k]};
-                std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-                std::vector<int32_t> key((size_t)npad);
-                for (int k = 0; k < npad; ++k) key[k] = order[std::min(k, n - 1)].second;  // odd counts repeat the last one
-                // identical lists are stored once: every interior cell of a box top / stair tread shares its neighbours' list
-                uint64_t first;
-                auto it = dedup.find(key);
-                if (it != dedup.end()) {
-                    first = it->second;
-                } else {
-                    first = refl.size() / 2;  // in refs (int2 units); always even (16-byte aligned pairs)
-                    dedup.emplace(key, first);
-                    const size_t base = refl.size();
-                    for (int k = 0; k < npad; ++k) {
-                        refl.push_back(key[k]);
-                        refl.push_back(0);
+            // ---- the cell's reference list: sorted by descending top (max z), ties by triangle id; each reference carries zrest = the
+            // highest top among the references AFTER it, so a downward ray stops as soon as its hit lies above what is left
+            const int npad = (n + 1) & ~1;
+            std::vector<std::pair<float, int32_t>> order((size_t)n);
+            for (int k = 0; k < n; ++k) order[k] = {ztop[(size_t)r[k]], r[k]};
+            std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            std::vector<int32_t> key((size_t)npad);
+            for (int k = 0; k < npad; ++k) key[k] = order[std::min(k, n - 1)].second;  // odd counts repeat the last one
+            // identical lists are stored once: every interior cell of a box top / stair tread shares its neighbours' list
+            uint64_t first;
+            auto it = dedup.find(key);
+            if (it != dedup.end()) {
+                first = it->second;
+            } else {
+                first = refl.size() / 2;  // in refs (int2 units); always even (16-byte aligned pairs)
+                dedup.emplace(key, first);
+                const size_t base = refl.size();
+                for (int k = 0; k < npad; ++k) {
+                    refl.push_back(key[k]);
+                    refl.push_back(0);
+                }
+                float suffix = -INFINITY;
+                for (int k = npad - 1; k >= 0; --k) {
+                    memcpy(&refl[base + (size_t)k * 2 + 1], &suffix, 4);
+                    if (k < n) suffix = std::max(suffix, order[k].first);
+                }
+            }
+            IMX_REQUIRE(first < (1ull << 31), "imx_mesh_create: too many cell references");
+            clist[(size_t)c * 2] = (int32_t)first;
+            clist[(size_t)c * 2 + 1] = npad;
+            ++n_general;
+            // ---- QH?  Only horizontal faces and axis-aligned walls in the list; at most one wall / face-edge line x = cx and one
+            // line y = cy through the interior; in each rectangle they cut, the faces at the highest height present cover it all.
+            bool qh = std::isfinite(order[0].first);
+            std::vector<std::array<double, 7>> hf;  // horizontal faces: 3 x (gx, gy), height
+            float cxw = INFINITY, cyw = INFINITY;   // split lines (world coordinates, the mesh's own floats)
+            double cxg = 0.0, cyg = 0.0;
+            const double mg = 0.5 * (double)IMX_GRID_TAU;
+            const double sx0 = ix + mg, sx1 = ix + 1 - mg, sy0 = iy + mg, sy1 = iy + 1 - mg;
+            for (int k = 0; k < n && qh; ++k) {
+                const float* rec = &recs[(size_t)r[k] * 12];
+                const bool horizontal = rec[2] == rec[5] && rec[5] == rec[8];
+                const bool wall = ztop[(size_t)r[k]] == -INFINITY;
+                if (!horizontal && !wall) { qh = false; break; }  // a sloped triangle: the Woop path
+                double g[3][2];
+                for (int cc = 0; cc < 3; ++cc) { g[cc][0] = grid_x(rec[cc * 3]); g[cc][1] = grid_y(rec[cc * 3 + 1]); }
+                if (horizontal) hf.push_back({g[0][0], g[0][1], g[1][0], g[1][1], g[2][0], g[2][1], (double)rec[2]});
+                for (int e = 0; e < 3 && qh; ++e) {  // axis-aligned edges that cross the interior are the only allowed height boundaries
+                    const int e2 = (e + 1) % 3;
+                    const float xa = rec[e * 3], ya = rec[e * 3 + 1], xb = rec[e2 * 3], yb = rec[e2 * 3 + 1];
+                    if (xa == xb && g[e][0] > sx0 && g[e][0] < sx1 && std::max(g[e][1], g[e2][1]) > sy0 && std::min(g[e][1], g[e2][1]) < sy1) {
+                        if (cxw == INFINITY) { cxw = xa; cxg = g[e][0]; } else if (cxw != xa) qh = false;
                     }
-                    float suffix = -INFINITY;
-                    for (int k = npad - 1; k >= 0; --k) {
-                        memcpy(&refl[base + (size_t)k * 2 + 1], &suffix, 4);
-                        if (k < n) suffix = std::max(suffix, order[k].first);
+                    if (ya == yb && g[e][1] > sy0 && g[e][1] < sy1 && std::max(g[e][0], g[e2][0]) > sx0 && std::min(g[e][0], g[e2][0]) < sx1) {
+                        if (cyw == INFINITY) { cyw = ya; cyg = g[e][1]; } else if (cyw != ya) qh = false;
                     }
                 }
-                // the first pair of references rides in the descriptor itself: an interior cell of a box top / tread needs
-                // descriptor -> two records and nothing else (the same two dependent levels as a lattice cell)
-                desc[(size_t)c * 4 + 1] = key[0];
-                desc[(size_t)c * 4 + 2] = key[1];
-                {
-                    float zr = -INFINITY;
-                    for (int k = 2; k < n; ++k) zr = std::max(zr, order[k].first);
-                    memcpy(&desc[(size_t)c * 4 + 3], &zr, 4);
-                }
-                // FLAT: the highest surface over the cell is horizontal -- faces whose three vertices share the height h = the list's
-                // highest top -- and those faces cover the whole interior of the cell (what a ray that is not within tau of a cell
-                // boundary can reach).  Everything else in the list lies at or below h, so a DOWNWARD vertical ray through the
-                // interior hits z = h whatever triangle it is: the descriptor alone answers it (bit 31 of id0 set, w = h) -- no
-                // record loads, no edge functions, no division.  Box tops, stair treads, platforms, the border ring.
-                {
-                    const float h = order[0].first;
-                    double area = 0.0;
-                    std::vector<std::array<std::array<double, 2>, 3>> flat;
-                    if (std::isfinite(h))
-                        for (int k = 0; k < n; ++k) {
-                            const float* rec = &recs[(size_t)r[k] * 12];
-                            if (rec[2] == h && rec[5] == h && rec[8] == h) {
-                                std::array<std::array<double, 2>, 3> t;
-                                for (int cc = 0; cc < 3; ++cc) {
-                                    t[cc][0] = ((double)rec[cc * 3] - (double)xmin) * (double)inv_cell;
-                                    t[cc][1] = ((double)rec[cc * 3 + 1] - (double)ymin) * (double)inv_cell;
-                                }
-                                flat.push_back(t);
-                            }
+            }
+            float hq[4] = {0, 0, 0, 0};
+            int32_t face_q = order[0].second;
+            if (qh) {
+                const double xs[3] = {sx0, cxw == INFINITY ? sx1 : cxg, sx1}, ys[3] = {sy0, cyw == INFINITY ? sy1 : cyg, sy1};
+                const int nxq = cxw == INFINITY ? 1 : 2, nyq = cyw == INFINITY ? 1 : 2;
+                for (int qy = 0; qy < 2 && qh; ++qy)
+                    for (int qx = 0; qx < 2 && qh; ++qx) {
+                        const int ux = qx < nxq ? qx : 0, uy = qy < nyq ? qy : 0;  // without a split both halves are the whole cell
+                        const double x0 = xs[ux], x1 = xs[ux + 1], y0 = ys[uy], y1 = ys[uy + 1];
+                        const double qa = (x1 - x0) * (y1 - y0);
+                        if (!(qa > 0.0)) { qh = false; break; }
+                        double top = -INFINITY;
+                        for (const auto& f : hf) {
+                            const double tri[3][2] = {{f[0], f[1]}, {f[2], f[3]}, {f[4], f[5]}};
+                            if (f[6] > top && clipped_area(tri, x0, y0, x1, y1) > 1e-9 * qa) top = f[6];
                         }
-                    const double m = 0.5 * (double)IMX_GRID_TAU;  // the square interior rays live in, grown a little
-                    const double x0 = ix + m, x1 = ix + 1 - m, y0 = iy + m, y1 = iy + 1 - m;
-                    bool covered = !flat.empty();
-                    for (const auto& t : flat) {
-                        const double tri[3][2] = {{t[0][0], t[0][1]}, {t[1][0], t[1][1]}, {t[2][0], t[2][1]}};
-                        area += clipped_area(tri, x0, y0, x1, y1);
-                    }
-                    covered = covered && area >= (x1 - x0) * (y1 - y0) * (1.0 - 1e-9);
-                    for (int sy = 0; sy < 5 && covered; ++sy)  // overlapping coplanar faces could fake the area: sample as well
-                        for (int sx = 0; sx < 5 && covered; ++sx) {
-                            const double qx = x0 + (x1 - x0) * sx / 4.0, qy = y0 + (y1 - y0) * sy / 4.0;
-                            bool in = false;
-                            for (const auto& t : flat) {
-                                const double tri[3][2] = {{t[0][0], t[0][1]}, {t[1][0], t[1][1]}, {t[2][0], t[2][1]}};
-                                if (point_in_tri(tri, qx, qy, 1e-9)) { in = true; break; }
+                        if (!std::isfinite(top)) { qh = false; break; }
+                        double cover = 0.0;
+                        for (const auto& f : hf)
+                            if (f[6] == top) {
+                                const double tri[3][2] = {{f[0], f[1]}, {f[2], f[3]}, {f[4], f[5]}};
+                                cover += clipped_area(tri, x0, y0, x1, y1);
                             }
-                            covered = in;
-                        }
-                    if (covered) {
-                        desc[(size_t)c * 4 + 1] |= (int32_t)0x80000000u;
-                        memcpy(&desc[(size_t)c * 4 + 3], &h, 4);  // replaces zrest: the general path of such a cell (rays on a cell
-                        ++n_flat;                                  // boundary, slanted rays) then simply never exits early on the first pair
+                        if (cover < qa * (1.0 - 1e-7)) { qh = false; break; }
+                        for (int sy = 0; sy < 3 && qh; ++sy)  // overlapping coplanar faces could fake the area: sample as well
+                            for (int sx = 0; sx < 3 && qh; ++sx) {
+                                const double px_ = x0 + (x1 - x0) * (0.1 + 0.4 * sx), py_ = y0 + (y1 - y0) * (0.1 + 0.4 * sy);
+                                bool in = false;
+                                for (const auto& f : hf)
+                                    if (f[6] == top) {
+                                        const double tri[3][2] = {{f[0], f[1]}, {f[2], f[3]}, {f[4], f[5]}};
+                                        if (point_in_tri(tri, px_, py_, 1e-9)) { in = true; break; }
+                                    }
+                                qh = in;
+                            }
+                        hq[qy * 2 + qx] = (float)top;
                     }
-                }
-                if (first < (1u << 24) && npad < 64) {  // first ref and count inline: no second table look-up
-                    desc[(size_t)c * 4] = (int32_t)(((uint32_t)first << 8) | ((uint32_t)npad << 2) | IMX_CELL_GENERAL);
-                } else {
-                    IMX_REQUIRE(gtab.size() / 2 < (1u << 29), "imx_mesh_create: too many general cells");
-                    desc[(size_t)c * 4] = (int32_t)(((uint32_t)(gtab.size() / 2) << 2) | IMX_CELL_GENERAL_IND);
-                    gtab.push_back((int32_t)first);
-                    gtab.push_back(npad);
-                }
-                ++n_general;
+            }
+            if (qh) {
+                memcpy(&ca[0], &hq[0], 16);  // h00 (x < cx, y < cy), h10 (x > cx), h01 (y > cy), h11
+                cb[0] = IMX_CELL_QH;
+                memcpy(&cb[1], &cxw, 4);
+                memcpy(&cb[2], &cyw, 4);
+                cb[3] = face_q;
+                ++n_flat;
+            } else {
+                // the first pair of references rides in the cell itself: {-, id0, id1, zrest after the pair}
+                ca[1] = key[0];
+                ca[2] = key[1];
+                float zr = -INFINITY;
+                for (int k = 2; k < n; ++k) zr = std::max(zr, order[k].first);
+                memcpy(&ca[3], &zr, 4);
+                cb[0] = IMX_CELL_GENERAL;
+                cb[1] = (int32_t)first;
+                cb[2] = npad;
             }
         }
+    for (auto& v : gxl) if (std::isnan(v)) v = 0.0f;  // lines no lattice cell uses
+    for (auto& v : gyl) if (std::isnan(v)) v = 0.0f;
     if (getenv("IMX_MESH_STATS")) {  // debugging aid: histogram of references per general cell
         std::vector<int64_t> hist(16, 0), histv(16, 0);
         int64_t degenerate = 0, total = 0;
         for (int64_t c = 0; c < ncell; ++c) {
             const int n = start[c + 1] - start[c];
-            if (n == 0 || (desc[(size_t)c * 4] & 3) == IMX_CELL_LATTICE) continue;
+            if (n == 0 || cellv[(size_t)c * 8 + 4] == IMX_CELL_LATTICE) continue;
             int nv = 0;
             for (int k = 0; k < n; ++k) {
                 const uint32_t* t = tris + 3 * (size_t)refs[start[c] + k];
@@ -332,7 +373,6 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         fprintf(stderr, "\n[imx mesh] degenerate (zero xy-area) refs %lld of %lld\n", (long long)degenerate, (long long)total);
     }
     IMX_REQUIRE(refl.size() / 2 < (1ull << 31), "imx_mesh_create: too many general cell references");
-    if (gtab.empty()) gtab.assign(2, 0);
     if (refl.empty()) refl.assign(4, 0);
 
     IMX_REQUIRE(imx_device_count() > 0, "imx_mesh_create: no GPU visible");
@@ -342,14 +382,15 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         IMX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     };
-    if (up((void**)&m->d_cell_desc, desc.data(), desc.size() * 4) || up((void**)&m->d_tile_pool, pool.data(), pool.size() * 4) ||
-        up((void**)&m->d_gtab, gtab.data(), gtab.size() * 4) || up((void**)&m->d_tri_rec, recs.data(), recs.size() * 4) ||
-        up((void**)&m->d_refs, refl.data(), refl.size() * 4))
+    if (up((void**)&m->d_cell, cellv.data(), cellv.size() * 4) || up((void**)&m->d_cell_list, clist.data(), clist.size() * 4) ||
+        up((void**)&m->d_gx, gxl.data(), gxl.size() * 4) || up((void**)&m->d_gy, gyl.data(), gyl.size() * 4) ||
+        up((void**)&m->d_tri_rec, recs.data(), recs.size() * 4) || up((void**)&m->d_refs, refl.data(), refl.size() * 4))
         return 1;
     m->v.refs = reinterpret_cast<const int4*>(m->d_refs);
-    m->v.cell_desc = reinterpret_cast<const int4*>(m->d_cell_desc);
-    m->v.tile_pool = reinterpret_cast<const float4*>(m->d_tile_pool);
-    m->v.gtab = reinterpret_cast<const int2*>(m->d_gtab);
+    m->v.cells = reinterpret_cast<const int4*>(m->d_cell);
+    m->v.cell_list = reinterpret_cast<const int2*>(m->d_cell_list);
+    m->v.gx = m->d_gx;
+    m->v.gy = m->d_gy;
     m->v.tri_rec = reinterpret_cast<const float4*>(m->d_tri_rec);
     m->v.nx = (int)nx; m->v.ny = (int)ny; m->v.ntx = ntx; m->v.nty = nty;
     m->v.x0 = xmin; m->v.y0 = ymin; m->v.cell = cell_size; m->v.inv_cell = inv_cell;
@@ -366,9 +407,10 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
 extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
     if (!m) return;
     if (m->d_tri_rec) (void)hipFree(m->d_tri_rec);
-    if (m->d_cell_desc) (void)hipFree(m->d_cell_desc);
-    if (m->d_tile_pool) (void)hipFree(m->d_tile_pool);
-    if (m->d_gtab) (void)hipFree(m->d_gtab);
+    if (m->d_cell) (void)hipFree(m->d_cell);
+    if (m->d_cell_list) (void)hipFree(m->d_cell_list);
+    if (m->d_gx) (void)hipFree(m->d_gx);
+    if (m->d_gy) (void)hipFree(m->d_gy);
     if (m->d_refs) (void)hipFree(m->d_refs);
     delete m;
 }
@@ -376,7 +418,7 @@ extern "C" void imx_mesh_destroy(imx_mesh_t* m) {
 extern "C" int imx_mesh_info(const imx_mesh_t* m, int64_t* info8) {
     IMX_REQUIRE(m && info8, "imx_mesh_info: null argument");
     info8[0] = m->v.nx; info8[1] = m->v.ny; info8[2] = m->v.F; info8[3] = m->num_refs; info8[4] = m->max_refs;
-    info8[5] = m->n_lattice; info8[6] = m->n_general;  // info8[6] includes the FLAT cells; their count rides in the upper half of info8[4]
+    info8[5] = m->n_lattice; info8[6] = m->n_general;  // info8[6] includes the QH cells; their count rides in the upper half of info8[4]
     info8[4] = (int64_t)m->max_refs | (m->n_flat << 32);
     int32_t b;
     memcpy(&b, &m->v.cell, 4); info8[7] = b;

@@ -607,6 +607,7 @@ class ManagerBasedRLEnv:
         names_t = [t.name for t in plan.termination_terms]
         self._log_views = {"Episode_Reward/" + n: self._log_out[i] for i, n in enumerate(names_r)}
         self._log_views.update({"Episode_Termination/" + n: self._log_out[len(names_r) + i] for i, n in enumerate(names_t)})
+        self._configure_gym_env_spaces()
         if seed is not None:
             self.seed(seed)
 
@@ -629,11 +630,38 @@ class ManagerBasedRLEnv:
         """Ascending ids of the envs reset in the last step (host sync: reads the device-side count)."""
         return self._reset_env_ids[: int(self._counters[0].item())]
 
-    @staticmethod
-    def seed(seed: int = -1) -> int:
+    def seed(self, seed: int = -1) -> int:
+        """ManagerBasedEnv.seed (envs/manager_based_env.py: torch / numpy seeding) -- and the seeds of the in-kernel generators
+        (observation noise, sensor drift; command and reset-event draws when the env owns those producers), so that "same seed, same
+        rollout" (isaaclab_tasks/test/test_environment_determinism.py:57-66) holds for seeds given after construction too."""
         torch.manual_seed(seed)
         np.random.seed(seed % (2 ** 32))
+        if getattr(self, "_counters", None) is not None:
+            self.noise_seed = int(seed) & 0xFFFFFFFFFFFF  # streams are keyed by (seed, step counter, env, column)
+            if getattr(self, "command_term", None) is not None:
+                self.command_term.seed = self.noise_seed
+            if getattr(self, "reset_events", None) is not None and hasattr(self.reset_events, "seed"):
+                self.reset_events.seed = self.noise_seed
         return seed
+
+    def _configure_gym_env_spaces(self):
+        """manager_based_rl_env.py:319-345: single_* spaces per env (Dict of Box per observation group, Box for the action) and their
+        batched forms.  gymnasium is used when importable; otherwise plain stand-ins with the same ``shape / low / high / dtype``."""
+        try:
+            import gymnasium as gym
+
+            box = lambda shape: gym.spaces.Box(low=-np.inf, high=np.inf, shape=shape)  # noqa: E731
+            dct = gym.spaces.Dict
+        except ImportError:
+            import types
+
+            box = lambda shape: types.SimpleNamespace(low=-np.inf, high=np.inf, shape=tuple(shape), dtype=np.float32)  # noqa: E731
+            dct = dict
+        N = self.num_envs
+        self.single_observation_space = dct({g.name: box((g.dim,)) for g in self.plan.obs_groups})
+        self.single_action_space = box((self.plan.action_dim,))
+        self.observation_space = dct({g.name: box((N, g.dim)) for g in self.plan.obs_groups})
+        self.action_space = box((N, self.plan.action_dim))
 
     def close(self):
         if getattr(self, "_plan_h", None):

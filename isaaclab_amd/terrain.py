@@ -12,27 +12,37 @@ from __future__ import annotations
 import numpy as np
 
 
+def _steeper(hf: np.ndarray, di: int, dj: int, thr: float) -> np.ndarray:
+    """mask[i, j] = 1 where the sample one step along (di, dj) lies more than ``thr`` ABOVE sample (i, j) (0 at the far border)."""
+    out = np.zeros(hf.shape)
+    ni, nj = hf.shape
+    src = hf[max(di, 0):ni + min(di, 0), max(dj, 0):nj + min(dj, 0)]   # the neighbour
+    dst = hf[max(-di, 0):ni + min(-di, 0), max(-dj, 0):nj + min(-dj, 0)]  # the sample itself
+    out[max(-di, 0):ni + min(-di, 0), max(-dj, 0):nj + min(-dj, 0)] = (src - dst) > thr
+    return out
+
+
 def height_field_to_mesh(height_field: np.ndarray, horizontal_scale: float, vertical_scale: float,
                          slope_threshold: float | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """Height samples on an x-major grid -> vertices + two triangles per cell, ``(i0, i3, i1)`` and ``(i0, i2, i3)`` -- the topology
+    of the reference's ``convert_height_field_to_mesh`` (isaaclab/terrains/height_field/utils.py:79-173), which the lattice cells of
+    the ray-caster rely on; pinned against that function by ``tests/golden/hf_mesh.npz``.  With a slope threshold a vertex at the foot of
+    a step steeper than the threshold slides one grid step towards the higher neighbour (along x, along y, or -- where neither
+    moved -- along the diagonal), which turns the steep quad into a vertical wall."""
     num_rows, num_cols = height_field.shape
-    y = np.linspace(0, (num_cols - 1) * horizontal_scale, num_cols)
     x = np.linspace(0, (num_rows - 1) * horizontal_scale, num_rows)
+    y = np.linspace(0, (num_cols - 1) * horizontal_scale, num_cols)
     yy, xx = np.meshgrid(y, x)
     hf = height_field.copy()
     if slope_threshold is not None:
         thr = slope_threshold * horizontal_scale / vertical_scale
-        move_x = np.zeros((num_rows, num_cols))
-        move_y = np.zeros((num_rows, num_cols))
-        move_c = np.zeros((num_rows, num_cols))
-        move_x[:-1, :] += hf[1:, :] - hf[:-1, :] > thr
-        move_x[1:, :] -= hf[:-1, :] - hf[1:, :] > thr
-        move_y[:, :-1] += hf[:, 1:] - hf[:, :-1] > thr
-        move_y[:, 1:] -= hf[:, :-1] - hf[:, 1:] > thr
-        move_c[:-1, :-1] += hf[1:, 1:] - hf[:-1, :-1] > thr
-        move_c[1:, 1:] -= hf[:-1, :-1] - hf[1:, 1:] > thr
-        xx = xx + (move_x + move_c * (move_x == 0)) * horizontal_scale
-        yy = yy + (move_y + move_c * (move_y == 0)) * horizontal_scale
-    vertices = np.zeros((num_rows * num_cols, 3), dtype=np.float32)
+        # +1: the next sample is higher (slide forward); -1: the previous one is (slide back)
+        shift_x = _steeper(hf, 1, 0, thr) - _steeper(hf, -1, 0, thr)
+        shift_y = _steeper(hf, 0, 1, thr) - _steeper(hf, 0, -1, thr)
+        shift_d = _steeper(hf, 1, 1, thr) - _steeper(hf, -1, -1, thr)
+        xx = xx + np.where(shift_x != 0, shift_x, shift_d) * horizontal_scale
+        yy = yy + np.where(shift_y != 0, shift_y, shift_d) * horizontal_scale
+    vertices = np.empty((num_rows * num_cols, 3), dtype=np.float32)
     vertices[:, 0] = xx.reshape(-1)
     vertices[:, 1] = yy.reshape(-1)
     vertices[:, 2] = hf.reshape(-1) * vertical_scale

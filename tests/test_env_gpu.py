@@ -583,3 +583,26 @@ def test_runner_with_a_critic_observation_group(mode):
     runner.learn(2)
     torch.cuda.synchronize()
     assert all(np.isfinite(x) for x in runner.alg.loss_dict().values())
+
+
+def test_seed_reseeds_the_in_kernel_generators_and_spaces_exist():
+    """isaaclab_tasks/test/test_environment_determinism.py:57-66 ("same seed, same rollout") through ``env.seed()`` / ``reset(seed=)``
+    given AFTER construction: the in-kernel observation-noise stream follows the seed.  Plus the gym spaces of
+    manager_based_rl_env.py:319-345."""
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    a = g.t("step0/action").cuda()
+
+    def rollout(seed):
+        env = make_env(g)
+        env.reset(seed=seed)
+        out = [env.step(a)[0]["policy"].clone() for _ in range(2)]
+        env.close()
+        return out
+
+    r1, r2, r3 = rollout(7), rollout(7), rollout(8)
+    assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+    assert not torch.equal(r1[0], r3[0])  # another seed, another noise stream
+    env = make_env(g)
+    assert tuple(env.single_action_space.shape) == (12,) and tuple(env.action_space.shape) == (64, 12)
+    assert tuple(env.single_observation_space["policy"].shape) == (48,) and tuple(env.observation_space["policy"].shape) == (64, 48)
+    env.close()
