@@ -172,18 +172,20 @@ IMX_DEV void vertical_tri(float ax_, float ay_, float az_, float bx_, float by_,
 
 // references [k0, end) of a cell's list, two per trip (one 16-byte load gives the next two ids); a downward ray stops once its hit
 // lies above everything that is left
+IMX_DEV void vertical_record(const MeshView& m, int id, float ox, float oy, float oz, bool flip, float Sz, float& best, int32_t& face) {
+    const float4* p = m.tri_rec + (size_t)id * 3;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz, best, face);
+}
+
+// (one record in flight at a time: after the LATTICE / QH cells this path serves well under 1 % of the rays, and what it would cost in
+// registers -- two 48-byte records live -- is paid by every wave of the observation kernel as lost occupancy)
 IMX_DEV void vertical_list(const MeshView& m, int k0, int end, float ox, float oy, float oz, bool flip, float Sz, float dz,
                            float& best, int32_t& face) {
     for (int k = k0; k < end; k += 2) {
         const int4 rr = m.refs[k >> 1];
-        const float4* p = m.tri_rec + (size_t)rr.x * 3;
-        const float4* p2 = m.tri_rec + (size_t)rr.z * 3;
-        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-        const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
-        vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
-                     best, face);
-        vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
-                     best, face);
+        vertical_record(m, rr.x, ox, oy, oz, flip, Sz, best, face);
+        vertical_record(m, rr.z, ox, oy, oz, flip, Sz, best, face);
         if (flip && face >= 0 && __int_as_float(rr.w) < oz + best * dz) break;
     }
 }
@@ -232,15 +234,9 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
             vertical_list(m, g.x, g.x + g.y, ox, oy, oz, flip, Sz, dz, best, face);
         }
     } else if (kind == IMX_CELL_GENERAL) {
-        // first pair straight from the cell: two shared triangle records (six 16-byte loads)
-        const float4* p = m.tri_rec + (size_t)a4.y * 3;
-        const float4* p2 = m.tri_rec + (size_t)a4.z * 3;
-        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-        const float4 r0 = p2[0], r1 = p2[1], r2 = p2[2];
-        vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), ox, oy, oz, flip, Sz,
-                     best, face);
-        vertical_tri(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, __float_as_int(r2.y), ox, oy, oz, flip, Sz,
-                     best, face);
+        // first pair straight from the cell
+        vertical_record(m, a4.y, ox, oy, oz, flip, Sz, best, face);
+        vertical_record(m, a4.z, ox, oy, oz, flip, Sz, best, face);
         // references are sorted by descending top; a4.w = highest top among those after this pair.  A downward
         // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
         if (flip && face >= 0 && __int_as_float(a4.w) < oz + best * dz) return;

@@ -737,9 +737,16 @@ IMX_DEV float obs_plain_value(const PlanView& P, const imx_state_t& S, const imx
 }
 
 // modifiers -> noise -> clip -> scale -> history window -> obs[e][c] for computed column i (observation_manager.py:305-335)
+// LEAN: the plan has one observation group, no modifiers and no history windows (every task config of BASELINE.json) -- the code for
+// those features is compiled out, which is worth registers (= resident waves) to every launch that does not need them.
+template <bool LEAN>
 IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& x, int i, float v, int64_t e, int corrupt,
                         bool fill_all, const float* __restrict__ noise_u, uint64_t seed, uint32_t step) {
     const int c = x.a.x;
+    if (LEAN) {
+        Bf.obs[e * P.gD[0] + c] = obs_post(x, v, corrupt & P.gcorrupt, noise_u, seed, step, e, P.D, 0);
+        return;
+    }
     const int g = (x.a.w >> 8) & 3;  // observation group of this column (ObservationManager.compute loops over the groups)
     const int gD = g == 0 ? P.gD[0] : (g == 1 ? P.gD[1] : (g == 2 ? P.gD[2] : P.gD[3]));
     const int gb = g == 0 ? 0 : (g == 1 ? P.gbase[1] : (g == 2 ? P.gbase[2] : P.gbase[3]));
@@ -764,7 +771,156 @@ IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& 
 }
 
 
+// The height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide whether
+// this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  One row per env
+// {timestamp, last update, drift xyz, data.pos_w z, outdated, step stamp}: wave 0 reads it (with the step counter, the reset flag and
+// everything else it needs: no load here depends on another), advances it once per step -- the stamp tells a repeated call within the
+// same step (ObservationManager.compute() by user code), which repeats the decision instead of advancing the clock again --, thread 0
+// writes it back, and the block's other waves take the outcome from LDS.  Called by every thread of the block (barrier inside).
+// In: px, py, pz = root position; out: the sensor position the rays start from / height_scan reads (data.pos_w).
+IMX_DEV void scanner_update(const PlanView& P, const imx_buffers_t& Bf, int64_t e, uint32_t step, bool fill_all, bool keep_all_hits,
+                            uint64_t seed, float& px, float& py, float& pz, bool& cast, bool& cache_z) {
+    __shared__ float s_scan[8];
+    if (threadIdx.x < 64) {
+        float* row = Bf.scan_state + (size_t)e * 8;
+        float ts = row[0], last = row[1], drx = row[2], dry = row[3], drz = row[4], pz_data = row[5];
+        bool outdated = row[6] != 0.0f;
+        const bool repeat = __float_as_uint(row[7]) == step + 1u;  // stamp = step + 1 (0 = never)
+        const bool was_reset = fill_all || Bf.reset_buf[e];
+        if (!repeat) {
+            for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
+            outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
+            if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
+                ts = 0.0f; last = 0.0f; outdated = true;
+                if (Bf.scan_drift_feed) {
+                    drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+                } else {
+                    const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
+                    drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
+                    dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
+                    drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+                }
+            }
+        } else {
+            outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
+        }
+        float keep = 0.0f;
+        if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
+            pz_data = pz + drz;
+            last = ts;
+            float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
+            for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
+            keep = (keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period)) ? 1.0f : 0.0f;
+        }
+        if (threadIdx.x == 0) {
+            float4* o = reinterpret_cast<float4*>(row);
+            o[0] = make_float4(ts, last, drx, dry);
+            o[1] = make_float4(drz, pz_data, 0.0f, __uint_as_float(step + 1u));
+            s_scan[0] = outdated ? 1.0f : 0.0f; s_scan[1] = keep; s_scan[2] = drx; s_scan[3] = dry; s_scan[4] = pz_data;
+        }
+    }
+    __syncthreads();
+    cast = s_scan[0] != 0.0f;
+    cache_z = s_scan[1] != 0.0f;
+    if (cast) { px += s_scan[2]; py += s_scan[3]; }
+    pz = s_scan[4];  // data.pos_w z of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
+}
+
+// One ray of the scanner: RayCaster._update_buffers_impl (ray_caster.py:242-260) -> hit height (+inf on a miss, ops.py:70)
 template <bool GENERAL_RAYS>
+IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __restrict__ es, const float* __restrict__ ray_local, int j,
+                       float px, float py, float pz, float yw, float yz, float* __restrict__ ray_hits_out, int64_t e) {
+    const float lx = ray_local[3 * j], ly = ray_local[3 * j + 1], lz = ray_local[3 * j + 2];
+    float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
+    if (P.ray_yaw_only) {
+        quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
+    } else {  // ray_caster.py:249-252: full orientation for starts and directions
+        quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
+        quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
+    }
+    sx += px; sy += py; sz += pz;
+    float t;
+    int32_t face;
+    const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
+                                  : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
+    const float hz = hit ? sz + t * dz : __builtin_huge_valf();  // kernels.py:69
+    if (ray_hits_out) {
+        float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
+        o[0] = hit ? sx + t * dx : __builtin_huge_valf();
+        o[1] = hit ? sy + t * dy : __builtin_huge_valf();
+        o[2] = hz;
+    }
+    return hz;
+}
+
+// The observation kernel of a LEAN plan with a height scanner (one observation group, no modifier programs, no history windows: every
+// rough-terrain task config of BASELINE.json).  Workgroup = env: RW ray waves + one column wave, side by side, no barrier between
+// them.  A ray lane casts ray j and finishes ITS height_scan column on the spot -- the term's offset / noise / clip / scale are the
+// same for all R columns, so they travel in scalar registers (one record, scalar loads) instead of a 16-word column record per lane;
+// the column wave fills the env's other columns (base velocity, joints, actions ...) meanwhile.  59 VGPRs: eight waves per SIMD.
+template <bool GENERAL_RAYS>
+__global__ void __launch_bounds__(1024)
+k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
+           const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G,
+           int scan_rec, int ray_threads) {
+    const int64_t e = blockIdx.x;
+    if (e == N) {  // the extra workgroup: the step tail k_term_rew deferred (its partials are complete: kernel boundary)
+        step_tail(P, N, Bf, sc, tail_G);
+        return;
+    }
+    const int32_t* __restrict__ W = P.w;
+    const uint32_t step = (uint32_t)Bf.counters[2];
+    const bool fill_all = (corrupt & 2) != 0;
+    const bool keep_all_hits = (corrupt & 8) != 0;
+    corrupt &= 1;
+    const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
+    float px = es[9], py = es[10], pz = es[11];
+    bool cast = true, cache_z = false;
+    const int D = P.gD[0];
+    // (Casting the rays BEFORE the scanner row is consulted -- legal without a drift range, and one round trip less on paper -- was
+    // measured: 23.6 us against 21.3; the barrier first, then rays and columns side by side, is the faster order.)
+    if (P.scan_stateful) scanner_update(P, Bf, e, step, fill_all, keep_all_hits, seed, px, py, pz, cast, cache_z);
+    if ((int)threadIdx.x < ray_threads) {
+        // height_scan (observations.py:165-173): sensor.data.pos_w z - hit z - offset, then noise -> clip -> scale (observation_manager.py:313-318)
+        const int32_t* r = W + P.obs_off + scan_rec * IMX_REC_WORDS;
+        const int out = r[IMX_R_OUT], flags = r[IMX_R_FLAGS];
+        const float off = f_of(r[IMX_R_P0]), nlo = f_of(r[IMX_R_NOISE_LO]), nhi = f_of(r[IMX_R_NOISE_HI]);
+        const float clo = f_of(r[IMX_R_CLIP_LO]), chi = f_of(r[IMX_R_CLIP_HI]), scale = f_of(r[IMX_R_SCALE]);
+        const bool noisy = (corrupt & P.gcorrupt) && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS));
+        const float* __restrict__ ray_local = reinterpret_cast<const float*>(W + P.ray_off);
+        const float yw = es[16], yz = es[17];
+        // one ray per lane (the host sizes ray_threads >= R)
+        const int j = (int)threadIdx.x;
+        const bool has = j < P.R;
+        float hz = 0.0f;
+        if (cast && has) hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
+        if (has) {
+            if (cast) {
+                if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
+            } else {
+                hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
+            }
+            float v = pz - hz - off;
+            const int c = out + j;
+            if (noisy) {
+                const float u = noise_u ? noise_u[e * P.D + c] : uniform01(seed, step, (uint64_t)e * P.D + c);
+                const float nz = u * (nhi - nlo) + nlo;  // noise_model.py:62-66
+                v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
+            }
+            if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);
+            if (flags & IMX_F_SCALE) v = v * scale;
+            Bf.obs[e * D + c] = v;
+        }
+    } else {
+        const int lanes = (int)blockDim.x - ray_threads;
+        for (int i = P.n_ray_cols + ((int)threadIdx.x - ray_threads); i < P.DC; i += lanes) {  // xcol lists the ray columns first
+            const XCol x = load_xcol(W, P.xcol_off, i);
+            obs_finish<true>(P, Bf, x, i, obs_plain_value(P, S, Bf, es, e, x), e, corrupt, fill_all, noise_u, seed, step);
+        }
+    }
+}
+
+template <bool GENERAL_RAYS, bool LEAN>
 __global__ void __launch_bounds__(256)
 k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
       const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G) {
@@ -785,67 +941,15 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
     float pz = es[11];
     const float yw = es[16], yz = es[17];
     float px = es[9], py = es[10];
-    // -- the height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide
-    //    whether this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  The
-    //    decision is a function of the env's state only, so every lane of the block takes the same one from the same (scalar) loads;
-    //    the state is double-buffered on the step counter: lanes read slot step&1, thread 0 writes the other -- a second call within
-    //    the same step (ObservationManager.compute() by user code) finds the same inputs and repeats the same outputs.
 #ifdef IMX_TRACE
     uint64_t trace_tp = 0;
 #endif
     bool cast = true, cache_z = false;
     if (P.scan_stateful) {
-        // One row per env {timestamp, last update, drift xyz, data.pos_w z, outdated, step stamp}: wave 0 reads it (with the step counter,
-        // the reset flag and everything else the block needs: no load here depends on another), advances it once per step -- the
-        // stamp tells a repeated call within the same step (ObservationManager.compute() by user code), which repeats the decision
-        // instead of advancing the clock again --, thread 0 writes it back, and the block's other waves take the outcome from LDS.
-        __shared__ float s_scan[8];
-        if (threadIdx.x < 64) {
-            float* row = Bf.scan_state + (size_t)e * 8;
-            float ts = row[0], last = row[1], drx = row[2], dry = row[3], drz = row[4], pz_data = row[5];
-            bool outdated = row[6] != 0.0f;
-            const bool repeat = __float_as_uint(row[7]) == step + 1u;  // stamp = step + 1 (0 = never)
-            const bool was_reset = fill_all || Bf.reset_buf[e];
-            if (!repeat) {
-                for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
-                outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
-                if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
-                    ts = 0.0f; last = 0.0f; outdated = true;
-                    if (Bf.scan_drift_feed) {
-                        drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
-                    } else {
-                        const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
-                        drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
-                        dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
-                        drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
-                    }
-                }
-            } else {
-                outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
-            }
-            float keep = 0.0f;
-            if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
-                pz_data = pz + drz;
-                last = ts;
-                float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
-                for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
-                keep = (keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period)) ? 1.0f : 0.0f;
-            }
-            if (threadIdx.x == 0) {
-                float4* o = reinterpret_cast<float4*>(row);
-                o[0] = make_float4(ts, last, drx, dry);
-                o[1] = make_float4(drz, pz_data, 0.0f, __uint_as_float(step + 1u));
-                s_scan[0] = outdated ? 1.0f : 0.0f; s_scan[1] = keep; s_scan[2] = drx; s_scan[3] = dry; s_scan[4] = pz_data;
-            }
-        }
-        __syncthreads();
+        scanner_update(P, Bf, e, step, fill_all, keep_all_hits, seed, px, py, pz, cast, cache_z);
 #ifdef IMX_TRACE
         trace_tp = wall_clock64();
 #endif
-        cast = s_scan[0] != 0.0f;
-        cache_z = s_scan[1] != 0.0f;
-        if (cast) { px += s_scan[2]; py += s_scan[3]; }
-        pz = s_scan[4];  // data.pos_w z of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
     }
 #ifdef IMX_TRACE
     const uint64_t trace_t0 = wall_clock64();
@@ -860,26 +964,7 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
         for (int j = threadIdx.x; j < P.R; j += blockDim.x) {
             float hz;
             if (cast) {
-                const float lx = ray_local[3 * j], ly = ray_local[3 * j + 1], lz = ray_local[3 * j + 2];
-                float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
-                if (P.ray_yaw_only) {
-                    quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
-                } else {  // ray_caster.py:249-252: full orientation for starts and directions
-                    quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
-                    quat_apply(es[12], es[13], es[14], es[15], P.rdx, P.rdy, P.rdz, dx, dy, dz);
-                }
-                sx += px; sy += py; sz += pz;
-                float t;
-                int32_t face;
-                const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
-                                              : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
-                hz = hit ? sz + t * dz : __builtin_huge_valf();  // kernels.py:69; misses stay +inf (ops.py:70)
-                if (ray_hits_out) {
-                    float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
-                    o[0] = hit ? sx + t * dx : __builtin_huge_valf();
-                    o[1] = hit ? sy + t * dy : __builtin_huge_valf();
-                    o[2] = hz;
-                }
+                hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
                 if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
             } else {
                 hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
@@ -903,15 +988,15 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
             const float hz = s_hz[j];
             v = pz - hz - f_of(x.b.x);
             // further height_scan terms on the same sensor (another group, another offset / noise / clip): same hit, own post-processing
-            for (int nx = x.c.z; nx != 0;) {
+            for (int nx = LEAN ? 0 : x.c.z; nx != 0;) {
                 const XCol tw = load_xcol(W, P.xcol_off, nx - 1);
-                obs_finish(P, Bf, tw, nx - 1, pz - hz - f_of(tw.b.x), e, corrupt, fill_all, noise_u, seed, step);
+                obs_finish<false>(P, Bf, tw, nx - 1, pz - hz - f_of(tw.b.x), e, corrupt, fill_all, noise_u, seed, step);
                 nx = tw.c.z;
             }
         } else {
             v = obs_plain_value(P, S, Bf, es, e, x);
         }
-        obs_finish(P, Bf, x, i, v, e, corrupt, fill_all, noise_u, seed, step);
+        obs_finish<LEAN>(P, Bf, x, i, v, e, corrupt, fill_all, noise_u, seed, step);
     }
 #ifdef IMX_TRACE
     if (g_trace && (threadIdx.x & 63) == 0) {
@@ -1092,6 +1177,7 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     // fit in three waves the remaining (cheap) columns ride as a second trip of the first lanes instead of a fourth wave
     int bs = plan->DC <= 64 ? 64 : (plan->DC <= 128 ? 128 : (plan->DC <= 192 ? 192 : 256));
     if (plan->DC > 192 && plan->n_ray_cols > 0 && plan->n_ray_cols <= 192 && plan->DC <= 2 * 192) bs = 192;
+    if (getenv("IMX_OBS_BS")) bs = atoi(getenv("IMX_OBS_BS"));
     const PlanView pv = imx_plan_view(plan);
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
@@ -1110,12 +1196,28 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     const size_t lds = (size_t)(pv.R > 0 ? pv.R : 1) * 4;
     const unsigned grid = (unsigned)N + (tail ? 1u : 0u);
-    if (vertical)
-        hipLaunchKernelGGL(k_obs<false>, dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv,
-                           frame, noise_u_d, seed, enable_corruption, ray_hits_out_d, sc, tail_G);
-    else
-        hipLaunchKernelGGL(k_obs<true>, dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv,
-                           frame, noise_u_d, seed, enable_corruption, ray_hits_out_d, sc, tail_G);
+    // the lean variant: one group, no modifier programs, no history windows (DC == D also rules out twin scan columns)
+    bool lean = plan->ngroups == 1 && plan->MS == 0 && plan->DC == plan->D && plan->DX == plan->DC;
+    for (int k = 0; k < plan->nobs && lean; ++k) lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & IMX_F_MODIFIERS);
+#define IMX_LAUNCH_OBS(G, L)                                                                                                     \
+    hipLaunchKernelGGL((k_obs<G, L>), dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed, \
+                       enable_corruption, ray_hits_out_d, sc, tail_G)
+    int scan_rec = -1;
+    for (int k = 0; k < plan->nobs; ++k)
+        if (w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) scan_rec = k;
+    if (lean && scan_rec >= 0 && pv.R > 0 && pv.R <= 64 * 15) {
+        // ray waves (at most 4: a lane then takes several rays) + one wave for the other columns
+        const int rw = (pv.R + 63) / 64;  // one ray per lane
+        const int threads = 64 * (rw + 1);
+        if (vertical)
+            hipLaunchKernelGGL(k_obs_lean<false>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d,
+                               seed, enable_corruption, ray_hits_out_d, sc, tail_G, scan_rec, 64 * rw);
+        else
+            hipLaunchKernelGGL(k_obs_lean<true>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d,
+                               seed, enable_corruption, ray_hits_out_d, sc, tail_G, scan_rec, 64 * rw);
+    } else if (vertical) { if (lean) IMX_LAUNCH_OBS(false, true); else IMX_LAUNCH_OBS(false, false); }
+    else { if (lean) IMX_LAUNCH_OBS(true, true); else IMX_LAUNCH_OBS(true, false); }
+#undef IMX_LAUNCH_OBS
     IMX_HIP(hipGetLastError());
     return 0;
 }
