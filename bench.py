@@ -127,7 +127,7 @@ def time_obs_kernel(env, launches=200):
     """Average duration of k_obs from HIP events on the stream it is launched on (torch's current stream)."""
     dev = env.device
     for _ in range(10):
-        env._compute_observations()  # k_frame + k_obs: the frame table of this state is current from here on
+        env._compute_observations()  # k_frame + the observation kernel: the frame table of this state is current from here on
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream(dev))
@@ -398,10 +398,10 @@ def main():
         out["env_step_path"] = {"value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
                                 "what": "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # PMC passes of tools/pmc_obs.py (same config)
+        tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # PMC passes of tools/pmc_obs.py (same config), see profiles/README.md
         if os.path.exists(tf) and args.num_envs == 4096 and args.task == TASK:
             traffic = json.load(open(tf)).get("k_obs_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "kernel": "k_obs<false> (observation assembly + fused height-scanner ray-cast)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_obs_lean<false> (observation assembly + fused height-scanner ray-cast)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6,
                            "peak_measured_copy": measured_copy_gbs(device)}  # GB/s of a 1 GiB device-to-device copy on this box
@@ -412,6 +412,12 @@ def main():
                 _, env_big, _ = build_env(args.task, big_n, device, 7, 1, tuple(args.terrain_tiles), mesh=env.terrain)
                 env_big.reset()
                 kb = time_obs_kernel(env_big, launches=50)
+                if os.environ.get("IMX_BENCH_DEBUG"):
+                    sys.stderr.write("large-n first %.1f us, again %.1f us\n" % (kb * 1e6, time_obs_kernel(env_big, launches=50) * 1e6))
+                    torch.cuda.synchronize()
+                    import gc; gc.collect(); torch.cuda.empty_cache()
+                    sys.stderr.write("large-n after empty_cache %.1f us\n" % (time_obs_kernel(env_big, launches=50) * 1e6))
+                    sys.stderr.write("mem allocated %.1f GB reserved %.1f GB\n" % (torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
                 out["roofline_large_n"] = {"num_envs": big_n, "kernel": out["roofline"]["kernel"], "avg_launch_us": kb * 1e6,
                                            "achieved": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9,
                                            "frac": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9 / HBM_PEAK_GBS,
@@ -422,8 +428,9 @@ def main():
         try:  # the largest hand-written kernel of the update, against the f32 MFMA peak
             mb = args.num_envs * T // int(runner.alg.num_mini_batches)
             out["roofline_mfma"] = time_mlp_dw(runner.alg, mb, device)
-            if os.path.exists(tf):
-                out["roofline_mfma"]["traffic"] = json.load(open(tf)).get("k_mlp_dw_bytes_per_launch")
+            tf1 = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # k_mlp_dw is unchanged since round 1
+            if os.path.exists(tf1):
+                out["roofline_mfma"]["traffic"] = json.load(open(tf1)).get("k_mlp_dw_bytes_per_launch")
         except Exception as exc:  # secondary measurement only
             out["roofline_mfma"] = {"error": str(exc)}
         out["ppo"] = {k: round(v, 6) for k, v in stats.items()}

@@ -95,6 +95,48 @@ class RolloutStorage:
         gae_returns(self.rewards, self.values, self.dones, last_values.contiguous(), gamma, lam, normalize_advantage,
                     self.returns, self.advantages, self._gae_scratch)
 
+    def _minibatch_setup(self, num_mini_batches):
+        """Sources, reusable destination buffers and argument arrays of the one-launch minibatch gather; the permutation lives in a
+        persistent buffer (fixed address: a captured gather reads whatever permutation was drawn into it last)."""
+        import ctypes
+
+        batch_size = self.num_envs * self.num_transitions_per_env
+        M = batch_size // num_mini_batches
+        srcs = [self.observations.flatten(0, 1)]
+        if self.privileged_observations is not None:
+            srcs.append(self.privileged_observations.flatten(0, 1))
+        srcs += [self.actions.flatten(0, 1), self.values.flatten(0, 1), self.advantages.flatten(0, 1),
+                 self.returns.flatten(0, 1), self.actions_log_prob.flatten(0, 1), self.mu.flatten(0, 1),
+                 self.sigma.flatten(0, 1)]
+        key = (M, len(srcs), num_mini_batches)
+        if getattr(self, "_mb_key", None) != key:
+            # wide rows (observations) start on 16-byte boundaries: the dW kernel of the first layer reads them with 16-byte loads
+            # even when the width is ragged (235 -> pitch 236: 81.8 -> 71.2 us, tools/dw_pitch.py); the views keep the true width
+            pitch = [(s.shape[1] + 3) // 4 * 4 if s.shape[1] >= 16 else s.shape[1] for s in srcs]
+            self._mb_dst = [torch.empty(M, p, device=self.device)[:, :s.shape[1]] for s, p in zip(srcs, pitch)]
+            self._mb_perm = torch.empty(num_mini_batches * M, dtype=torch.int64, device=self.device)
+            n = len(srcs)
+            self._mb_args = ((ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]), (ctypes.c_void_p * n)(*[d.data_ptr() for d in self._mb_dst]),
+                             (ctypes.c_int32 * n)(*[s.shape[1] for s in srcs]), (ctypes.c_int32 * n)(*[d.stride(0) for d in self._mb_dst]), n, M)
+            self._mb_key = key
+        return self._mb_args
+
+    def draw_permutation(self, num_mini_batches):
+        """A fresh random permutation of the T*N transitions into the persistent index buffer (upstream: torch.randperm per update)."""
+        self._minibatch_setup(num_mini_batches)
+        torch.randperm(self._mb_perm.numel(), out=self._mb_perm)
+        return self._mb_perm
+
+    def gather_minibatch(self, i, num_mini_batches, stream=None):
+        """Minibatch ``i`` of the permutation in the index buffer -> the reusable batch buffers (ONE ``imx_gather_rows`` launch); returns
+        (obs, critic_obs, actions, values, advantages, returns, old_log_prob, old_mu, old_sigma)."""
+        src_p, dst_p, widths, pitches, n, M = self._minibatch_setup(num_mini_batches)
+        idx = self._mb_perm[i * M:(i + 1) * M]
+        st = _lib.current_stream(torch.device(self.device)) if stream is None else stream
+        check(lib().imx_gather_rows_pitched(M, idx.data_ptr(), n, src_p, dst_p, widths, pitches, st))
+        dst = self._mb_dst
+        return tuple(dst) if self.privileged_observations is not None else (dst[0], dst[0]) + tuple(dst[1:])
+
     def mini_batch_generator(self, num_mini_batches, num_epochs=8, copy_stream=None):
         """Yields (obs, critic_obs, actions, values, advantages, returns, old_log_prob, old_mu, old_sigma) minibatches
         of a random permutation of the T*N transitions; the nine gathers are ONE ``imx_gather_rows`` launch into
@@ -102,44 +144,15 @@ class RolloutStorage:
         that stream (after everything enqueued on the current stream so far) and ``(batch, ready_event)`` is yielded: the
         caller requests the next minibatch right after the backward pass and waits for ``ready_event`` only before it
         uses the data, so the HBM-bound gather runs beside the optimiser step instead of in front of the next forward."""
-        import ctypes
-
-        batch_size = self.num_envs * self.num_transitions_per_env
-        M = batch_size // num_mini_batches
-        indices = torch.randperm(num_mini_batches * M, requires_grad=False, device=self.device)
-        srcs = [self.observations.flatten(0, 1)]
-        if self.privileged_observations is not None:
-            srcs.append(self.privileged_observations.flatten(0, 1))
-        srcs += [self.actions.flatten(0, 1), self.values.flatten(0, 1), self.advantages.flatten(0, 1),
-                 self.returns.flatten(0, 1), self.actions_log_prob.flatten(0, 1), self.mu.flatten(0, 1),
-                 self.sigma.flatten(0, 1)]
-        key = (M, len(srcs))
-        if getattr(self, "_mb_key", None) != key:
-            # wide rows (observations) start on 16-byte boundaries: the dW kernel of the first layer reads them with 16-byte loads
-            # even when the width is ragged (235 -> pitch 236: 81.8 -> 71.2 us, tools/dw_pitch.py); the views keep the true width
-            pitch = [(s.shape[1] + 3) // 4 * 4 if s.shape[1] >= 16 else s.shape[1] for s in srcs]
-            self._mb_dst = [torch.empty(M, p, device=self.device)[:, :s.shape[1]] for s, p in zip(srcs, pitch)]
-            self._mb_key = key
-        dst = self._mb_dst
-        n = len(srcs)
-        src_p = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
-        dst_p = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dst])
-        widths = (ctypes.c_int32 * n)(*[s.shape[1] for s in srcs])
-        pitches = (ctypes.c_int32 * n)(*[d.stride(0) for d in dst])
-        L = lib()
-        stream = _lib.current_stream(torch.device(self.device))
+        self.draw_permutation(num_mini_batches)
         main = torch.cuda.current_stream(torch.device(self.device)) if copy_stream is not None else None
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
-                idx = indices[i * M:(i + 1) * M]
                 if copy_stream is not None:
                     copy_stream.wait_stream(main)
-                    stream = copy_stream.cuda_stream
-                check(L.imx_gather_rows_pitched(M, idx.data_ptr(), n, src_p, dst_p, widths, pitches, stream))
-                batch = tuple(dst) if self.privileged_observations is not None else (dst[0], dst[0]) + tuple(dst[1:])
-                if copy_stream is not None:
+                    batch = self.gather_minibatch(i, num_mini_batches, copy_stream.cuda_stream)
                     ready = torch.cuda.Event()
                     ready.record(copy_stream)
                     yield batch, ready
                 else:
-                    yield batch
+                    yield self.gather_minibatch(i, num_mini_batches)
