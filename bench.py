@@ -383,7 +383,9 @@ def main():
                    "parallelism": f"dp{world}", "rollout": "eager" if args.no_graph else "hipGraph",
                    "update": ("hipGraph" if getattr(runner.alg, "_update_g", None) is not None else "eager")
                    + (" (measured eager %.2f ms, graph %.2f ms)" % runner.alg._update_times_ms if hasattr(runner.alg, "_update_times_ms") else ""),
-                   "policy_params": runner.alg.bucket.numel},
+                   "policy_params": runner.alg.bucket.numel,
+                   "obs_noise": "in-kernel counter-based generator (range / determinism property-tested; the parity tests feed the "
+                                "reference's recorded uniforms through the same kernel)"},
         "phase_ms": {"collect_plus_gae": collect_ms, "update": update_ms},
         "ms_per_step_per_rank": rank_ms,
         "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "distinct_gpus": 1 if rehearsal else world,

@@ -659,8 +659,9 @@ class PPO:
         Rough-Anymal-C 17.7 -> 17.3 ms) but the runtime's own placement of the three branches can lose to the hand-ordered eager
         issue (Rough-G1: 21.7 -> 24.4 ms).  So it is measured, once: call 1 eager (allocations, GEMM tuning), call 2 eager between
         two events, call 3 capture + replay, call 4 replay between two events, and from call 5 on the faster of the two."""
-        if self.update_graph and self.device.type == "cuda" and self.is_multi_gpu and not self.normalize_advantage_per_mini_batch:
-            return self._update_segments()
+        if (self.update_graph == "segments" and self.device.type == "cuda" and self.is_multi_gpu
+                and not self.normalize_advantage_per_mini_batch):
+            return self._update_segments()  # opt-in (IMX_UPDATE_GRAPH=segments): measured SLOWER than the eager update, see _update_segments
         if not (self.update_graph and self.device.type == "cuda" and not self.is_multi_gpu) or self._update_t == "eager":
             return self._update_eager()
         self._update_calls += 1
@@ -710,8 +711,11 @@ class PPO:
         minibatch index: the index slice is baked in, the permutation buffer it points into is redrawn eagerly per update), the
         bucket all-reduce issued eagerly between the graphs (RCCL is never captured), one replay of [grad norm + adaptive-KL rule +
         Adam] (the same graph for every minibatch).  Same kernels, same order, same arithmetic as ``_update_eager`` -- the replays only
-        remove the host's ~1200 launches per update from the critical path, which is what the eager multi-GPU update lost against the
-        single-GPU replay (17.7-18.0 ms against 17.4).  First call eager (allocations, GEMM tuning), second call captures."""
+        remove the host's ~1200 launches per update from the critical path.  First call eager (allocations, GEMM tuning), second call
+        captures.  MEASURED (single-rank RCCL group, bench.py with IMX_FORCE_DIST=1): 30.6 ms per update against 18.0 ms eager -- 40
+        launches of three-stream graphs per update cost more in launch latency than the host's 1200 kernel launches they replace, and the
+        rollout graph next to them slowed down too (3.1 -> 6.6 ms).  So this is NOT the default for N > 1 (the eager update is); it stays
+        as an option (``update_graph = "segments"`` / ``IMX_UPDATE_GRAPH=segments``) with its bit-exactness tests."""
         self._seg_calls += 1
         if self._seg_calls == 1:
             return self._update_eager()

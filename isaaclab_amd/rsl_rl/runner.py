@@ -92,6 +92,8 @@ class OnPolicyRunner:
         self.tot_time = 0.0
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self.alg.update_graph = self.use_graph and os.getenv("IMX_UPDATE_GRAPH", "1") != "0"
+        if self.alg.update_graph and os.getenv("IMX_UPDATE_GRAPH") == "segments":
+            self.alg.update_graph = "segments"  # N > 1 only: per-minibatch graph segments (measured slower than eager; opt-in)
         self._graph = None
         N = self.env.num_envs
         self._cur_reward_sum = torch.zeros(N, device=self.device)
@@ -131,6 +133,18 @@ class OnPolicyRunner:
                                     rank=self.gpu_global_rank, world_size=self.gpu_world_size)
         if self.device.type == "cuda":
             torch.cuda.set_device(0 if rehearsal else self.gpu_local_rank)
+            # the update keeps three HIP streams busy and RCCL adds its own: with ROCm's default of 4 hardware queues two of them share
+            # one (+14 % update time, tools/dist_overhead.py).  The package sets GPU_MAX_HW_QUEUES=8 at import unless HIP was already
+            # up or the user chose a value: say so instead of silently running slower.
+            try:
+                q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+            except ValueError:
+                q = 4
+            if q < 8 and self.gpu_global_rank == 0:
+                import warnings
+
+                warnings.warn(f"GPU_MAX_HW_QUEUES={q}: the data-parallel update wants 8 hardware queues (export it before the first HIP call, "
+                              "or import isaaclab_amd before torch.cuda is touched); continuing, ~10 % slower updates", RuntimeWarning)
 
     # ---- rollout ---------------------------------------------------------------------------------------------------
     def _fusable(self) -> bool:

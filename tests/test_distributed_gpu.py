@@ -27,7 +27,7 @@ def _worker(rank, world, port, out, segments=False):
     alg = PPO(pol, device="cuda:0", multi_gpu_cfg={"global_rank": rank, "local_rank": rank, "world_size": world}, num_learning_epochs=2,
               num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005, max_grad_norm=1.0,
               clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
-    alg.update_graph = segments  # per-minibatch hipGraph segments, the all-reduce eager between them
+    alg.update_graph = "segments" if segments else False  # per-minibatch hipGraph segments, the all-reduce eager between them
     alg.init_storage("rl", N, T, (D,), (0,), (A,))
     alg.broadcast_parameters()
     g = torch.Generator().manual_seed(500 + rank)  # each rank its own rollout

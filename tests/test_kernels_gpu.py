@@ -708,7 +708,7 @@ def test_update_through_the_rccl_path_single_rank(libimx):
 
     def run(multi, segments=False, iters=2):
         alg = PPO(copy.deepcopy(pol0), device="cuda:0", multi_gpu_cfg={"global_rank": 0, "local_rank": 0, "world_size": 1} if multi else None, **kw)
-        alg.update_graph = segments  # multi-GPU + update_graph: per-minibatch hipGraph segments with the eager all-reduce between them
+        alg.update_graph = "segments" if segments else False  # multi-GPU + update_graph: per-minibatch hipGraph segments with the eager all-reduce between them
         alg.init_storage("rl", N, T, (D,), (0,), (A,))
         torch.manual_seed(77)
         for it in range(iters):
