@@ -201,7 +201,9 @@ typedef struct imx_buffers {
     uint8_t* truncated;          /* (N) */
     uint8_t* reset_buf;          /* (N) */
     int64_t* reset_env_ids;      /* (N) ascending ids of reset envs; valid prefix = counters[0] */
-    int32_t* counters;           /* (8) [0] reset count [1] ticket [2] step counter (RNG) [3..] reserved */
+    int32_t* counters;           /* (8) [0] reset count [1] ticket [2] step counter (RNG streams, sensor stamps): imx_terminations_rewards
+                                    publishes [3] + 1 there [3] its shadow, written by imx_observations (a step = one of each)
+                                    [4],[5] low / high word of the sensor-drift seed (caller-written) [6..] reserved */
     float* log_out;              /* (NREW_ALL + NTERM + 1) Episode_Reward/<term>, Episode_Termination/<term>, count */
     float* obs;                  /* (N,D_0) first observation group; managers/observation_manager.py:238-335 */
     void* scratch;               /* imx_plan_scratch_bytes(plan, N) bytes */
@@ -211,9 +213,10 @@ typedef struct imx_buffers {
     float* obs_extra3;           /* (N,D_3) */
     float* scan_state;           /* (N,8) [timestamp, timestamp_last_update, drift xyz, data.pos_w z, outdated, step stamp] of the
                                     height scanner; required when IMX_H_SCAN_STATEFUL; the caller starts it with zeros and
-                                    outdated = 1 (sensors start outdated, sensor_base.py _initialize_impl).  The stamp (counters[2] + 1
-                                    as uint bits) makes a second imx_observations call within one step repeat the first one's decision
-                                    instead of advancing the sensor clock again */
+                                    outdated = 1 (sensors start outdated, sensor_base.py _initialize_impl).  The sensor clock is advanced
+                                    where the env's frame row is produced: by imx_terminations_rewards (which knows the step's reset
+                                    flags) or, without it, by imx_observations.  The stamp (counters[2] + 1 as uint bits) makes a
+                                    second call within one step repeat the first one's decision instead of advancing the clock again */
     float* scan_hit_z;           /* (N,R) data.ray_hits_w[..., 2] kept for envs whose sensor is not outdated at the next step */
     const float* scan_drift_feed;/* optional (N,3): drift values taken at a sensor reset instead of the in-kernel draw (parity runs) */
 } imx_buffers_t;
@@ -250,7 +253,10 @@ int imx_action_process(const imx_plan_t* plan, int64_t num_envs, const float* ac
  * flags bit 0: leave the end of the step -- reset_env_ids, the reset count (counters[0]) and the Episode_* entries of log_out,
  * which need every env group's partial results -- to the imx_observations call that follows on the same stream (its
  * enable_corruption bit 4): a kernel boundary then orders them instead of a fence + ticket inside this launch.  Masks, rewards,
- * episodic sums and the reset of manager state are complete either way. */
+ * episodic sums and the reset of manager state are complete either way.
+ * With state->root_pos_w present the launch also leaves the per-env frame rows (body-frame velocities, projected gravity, the
+ * height scanner's update decision: SensorBase.update / reset, sensors/sensor_base.py:182-205) imx_observations reads when called
+ * with enable_corruption bit 2. */
 int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state,
                              const imx_buffers_t* buf, int flags, imx_stream_t stream);
 

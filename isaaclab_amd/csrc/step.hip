@@ -134,7 +134,8 @@ static inline StepScratch carve(void* base, int64_t N, int KA, int NT) {
 }
 
 // per-env frame table written by k_frame, read by k_obs: IMX_ES_WORDS floats per env, behind the step scratch
-#define IMX_ES_WORDS 20
+#define IMX_ES_WORDS 24  // 0-2 lin vel b, 3-5 ang vel b, 6-8 projected gravity, 9-11 root pos, 12-15 root quat, 16-17 scanner yaw quat (w, z),
+                         // 18-19 free, 20 scanner flags (1 = cast this step, 2 = keep the hit heights), 21-22 sensor x / y, 23 data.pos_w z
 static inline size_t frame_offset_bytes(const imx_plan_t* plan, int64_t N) {
     const size_t b = 4 * step_scratch_words(N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
     return (b + 255) & ~(size_t)255;
@@ -179,6 +180,51 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
     }
 }
 
+// The height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide whether
+// this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  One row per env
+// {timestamp, last update, drift xyz, data.pos_w z, outdated, step stamp}, advanced by ONE lane per env where the env's frame row is
+// produced (the step kernel, which knows the reset flag, or k_frame) -- the observation kernel only reads the outcome from the frame
+// row with its other scalar loads: no barrier, no extra round trip there.  The stamp tells a repeated call within the same step
+// (ObservationManager.compute() by user code), which repeats the decision instead of advancing the clock again.
+// Returns {flags (1 cast, 2 keep hit heights), sensor x, sensor y, data.pos_w z}.
+IMX_DEV float4 scanner_step(const PlanView& P, const imx_buffers_t& Bf, int64_t e, uint32_t step, bool was_reset, float rx, float ry, float rz) {
+    if (!P.scan_stateful) return make_float4(1.0f, rx, ry, rz);
+    const uint64_t seed = (uint64_t)(uint32_t)Bf.counters[4] | ((uint64_t)(uint32_t)Bf.counters[5] << 32);  // the caller's drift seed
+    float* row = Bf.scan_state + (size_t)e * 8;
+    float ts = row[0], last = row[1], drx = row[2], dry = row[3], drz = row[4], pz_data = row[5];
+    bool outdated = row[6] != 0.0f;
+    const bool repeat = __float_as_uint(row[7]) == step + 1u;  // stamp = step + 1 (0 = never)
+    if (!repeat) {
+        for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
+        outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
+        if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
+            ts = 0.0f; last = 0.0f; outdated = true;
+            if (Bf.scan_drift_feed) {
+                drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+            } else {
+                const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
+                drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
+                dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
+                drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+            }
+        }
+    } else {
+        outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
+    }
+    float flags = 0.0f;
+    if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
+        pz_data = rz + drz;
+        last = ts;
+        float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
+        for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
+        flags = !(ts2 - last + 1.0e-6f >= P.scan_period) ? 3.0f : 1.0f;
+    }
+    float4* o = reinterpret_cast<float4*>(row);
+    o[0] = make_float4(ts, last, drx, dry);
+    o[1] = make_float4(drz, pz_data, 0.0f, __uint_as_float(step + 1u));
+    return make_float4(flags, rx + (outdated ? drx : 0.0f), ry + (outdated ? dry : 0.0f), pz_data);
+}
+
 #ifdef IMX_TRACE  // tools/trace_kobs.py only: per-wave start / end stamps (100 MHz wall clock) and placement; never in libimx.so
 __device__ uint64_t* g_trace = nullptr;
 extern "C" int imx_debug_trace(uint64_t* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)); }
@@ -194,7 +240,9 @@ extern "C" int imx_debug_trace(uint64_t* buf) { return (int)hipMemcpyToSymbol(HI
 // (reward_manager.py:115-121, termination_manager.py:142-144) in a fixed order (deterministic, no float atomics).  ONE workgroup
 // runs it after every group's partials are visible: the last-arriving workgroup of k_term_rew, or -- inside env.step() -- an extra
 // workgroup of the observation kernel that follows (a kernel boundary instead of a fence + ticket: 4.9 us off the step kernel).
-IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, const StepScratch& sc, int G) {
+// The work splits in `nparts` workgroups so that it can ride along a kernel of small workgroups: part 0 orders the reset ids, parts
+// 1.. share the log entries (each wave re-derives the reset count from the group counts: a handful of loads); nparts == 1 does both.
+IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, const StepScratch& sc, int G, int part, int nparts) {
     __shared__ int s_scan[IMX_TR_MAX_WAVES];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -202,35 +250,44 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
     const int nw = (int)((N + G - 1) / G);
     const int TB = blockDim.x;
     const int t = threadIdx.x;
-    // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + per-wave totals
-    const int chunk = (nw + TB - 1) / TB;
-    int local = 0;
-    for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) local += __builtin_nontemporal_load(&sc.wave_cnt[w]);
-    int incl = local;
+    int total = 0;
+    if (part == 0) {
+        // exclusive scan of group counts: thread t owns groups [t*chunk, (t+1)*chunk); wave shuffles + per-wave totals
+        const int chunk = (nw + TB - 1) / TB;
+        int local = 0;
+        for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) local += __builtin_nontemporal_load(&sc.wave_cnt[w]);
+        int incl = local;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) s_scan[wv] = incl;
-    __syncthreads();
-    int wave_base = 0, total = 0;
-    for (int w = 0; w < NW; ++w) {
-        if (w < wv) wave_base += s_scan[w];
-        total += s_scan[w];
-    }
-    if (t == 0) Bf.counters[0] = total;  // number of reset envs
-    int off = wave_base + incl - local;
-    for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
-        const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
-        for (int j = 0; j < c; ++j)
-            Bf.reset_env_ids[off + j] = (int64_t)w * G + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
-        off += c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_scan[wv] = incl;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < NW; ++w) {
+            if (w < wv) wave_base += s_scan[w];
+            total += s_scan[w];
+        }
+        if (t == 0) Bf.counters[0] = total;  // number of reset envs
+        int off = wave_base + incl - local;
+        for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
+            const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
+            for (int j = 0; j < c; ++j)
+                Bf.reset_env_ids[off + j] = (int64_t)w * G + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
+            off += c;
+        }
+        if (total > 0 && t == 0) Bf.log_out[P.nrew_all + P.nterm] = (float)total;
+        if (nparts > 1) return;
+    } else {
+        for (int w = lane; w < nw; w += 64) total += __builtin_nontemporal_load(&sc.wave_cnt[w]);
+        total = wave_sum_i(total);
     }
     if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
         // one wave per log entry: lanes stride over the groups, fixed-shape shuffle tree -> deterministic
         const int nlog = P.nrew_all + P.nterm;
-        for (int k = wv; k < nlog; k += NW) {
+        const int first = nparts > 1 ? (part - 1) * NW + wv : wv, stride = nparts > 1 ? (nparts - 1) * NW : NW;
+        for (int k = first; k < nlog; k += stride) {
             if (k < P.nrew_all) {
                 float s = 0.0f;
                 for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
@@ -244,7 +301,6 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
                 if (lane == 0) Bf.log_out[k] = (float)s;
             }
         }
-        if (t == 0) Bf.log_out[nlog] = (float)total;
     }
 }
 
@@ -277,8 +333,12 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     const int J = P.J, Bn = P.B, H = P.H, A = P.A;
     const int nterm = P.nterm, nrew = P.nrew;
     const int32_t* __restrict__ W = P.w;  // term tables: wave-uniform addresses -> scalar loads (L2-resident, a few KB)
+    // The step counter (keys the in-kernel random streams, stamps the sensor rows) is advanced here without a read-modify-write race:
+    // this kernel reads the shadow counters[3] the last observation launch left and publishes counters[2] = shadow + 1; the observation
+    // kernel reads counters[2] and writes the shadow.
+    const uint32_t step = (uint32_t)Bf.counters[3] + 1u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) Bf.counters[2] = (int32_t)step;
     IMX_STAMP(0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) Bf.counters[2] += 1;  // step counter (keys the noise streams of the kernels that follow)
     // LDS: [termination values: nterm x 64 u32 (bit 0 value, bit 1 time-out term)][f: nrew x 64][es: nrew x 64][val: nrew x 64];
     // every slot is written by exactly one wave before the barrier that publishes it: no zero fill, no atomics
     uint32_t* s_tv = reinterpret_cast<uint32_t*>(smem);
@@ -312,9 +372,10 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
         o[3] = q4;
         o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
         if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(qw, qx, qy, qz, o[4].x, o[4].y);
-        float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
+        float4* dst = reinterpret_cast<float4*>(frame) + e * 6;
 #pragma unroll
         for (int k = 0; k < 5; ++k) dst[k] = o[k];
+        if (P.R > 0 && !P.scan_stateful) dst[5] = make_float4(1.0f, o[2].y, o[2].z, o[2].w);  // a sensor without clock: cast, from the root
     }
     IMX_STAMP(1);
     IMX_STAMP(2);
@@ -494,6 +555,10 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     }
     const bool truncated = (term_bits & trunc_mask) != 0u, terminated = (term_bits & ~trunc_mask) != 0u;
     const bool reset = live && (terminated || truncated);
+    if (frame && P.scan_stateful && wv == NW - 1 && live) {  // the sensor's clock, now that the env's reset flag is known (scene.reset(env_ids))
+        reinterpret_cast<float4*>(frame)[e * 6 + 5] =
+            scanner_step(P, Bf, e, step, reset, S.root_pos_w[e * 3], S.root_pos_w[e * 3 + 1], S.root_pos_w[e * 3 + 2]);
+    }
     // RewardManager.compute (reward_manager.py:128-157): value = f * w * dt; sums += value; step_reward = value/dt
     const float dt = P.step_dt;
     for (int k = wv; k < nrew; k += NW) {
@@ -580,7 +645,7 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     }
     __syncthreads();
     if (!s_last) return;
-    step_tail(P, N, Bf, sc, G);
+    step_tail(P, N, Bf, sc, G, 0, 1);
 }
 
 // ------------------------------------------------------------------------------------------------- observations
@@ -682,7 +747,7 @@ IMX_DEV float apply_modifiers(const int32_t* __restrict__ W, int xmod, float v, 
 // projected_gravity_b), sensor position and the yaw-only sensor quaternion (yaw_quat, utils/math.py:521-542), once per
 // env per step instead of once per wave of k_obs (PMC: the transcendental prologue was ~40 % of k_obs's VALU work).
 __global__ void __launch_bounds__(64)
-k_frame(PlanView P, int64_t N, imx_state_t S, float* __restrict__ frame) {
+k_frame(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, float* __restrict__ frame, int fill_all) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[e];
@@ -696,9 +761,11 @@ k_frame(PlanView P, int64_t N, imx_state_t S, float* __restrict__ frame) {
     o[3] = q4;
     o[4] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     if (P.R > 0 && P.ray_yaw_only) yaw_quat_wz(q4.x, q4.y, q4.z, q4.w, o[4].x, o[4].y);
-    float4* dst = reinterpret_cast<float4*>(frame) + e * 5;
+    float4* dst = reinterpret_cast<float4*>(frame) + e * 6;
 #pragma unroll
     for (int k = 0; k < 5; ++k) dst[k] = o[k];
+    if (P.R > 0)
+        dst[5] = scanner_step(P, Bf, e, (uint32_t)Bf.counters[2], fill_all || (Bf.reset_buf && Bf.reset_buf[e]), o[2].y, o[2].z, o[2].w);
 }
 
 // k_obs: one BLOCK = one environment, one lane = one output column (ray columns first in xcol).  No prologue, no
@@ -771,61 +838,6 @@ IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& 
 }
 
 
-// The height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide whether
-// this env's rays are cast this step (update_period), a per-env drift re-drawn at reset moves the sensor frame.  One row per env
-// {timestamp, last update, drift xyz, data.pos_w z, outdated, step stamp}: wave 0 reads it (with the step counter, the reset flag and
-// everything else it needs: no load here depends on another), advances it once per step -- the stamp tells a repeated call within the
-// same step (ObservationManager.compute() by user code), which repeats the decision instead of advancing the clock again --, thread 0
-// writes it back, and the block's other waves take the outcome from LDS.  Called by every thread of the block (barrier inside).
-// In: px, py, pz = root position; out: the sensor position the rays start from / height_scan reads (data.pos_w).
-IMX_DEV void scanner_update(const PlanView& P, const imx_buffers_t& Bf, int64_t e, uint32_t step, bool fill_all, bool keep_all_hits,
-                            uint64_t seed, float& px, float& py, float& pz, bool& cast, bool& cache_z) {
-    __shared__ float s_scan[8];
-    if (threadIdx.x < 64) {
-        float* row = Bf.scan_state + (size_t)e * 8;
-        float ts = row[0], last = row[1], drx = row[2], dry = row[3], drz = row[4], pz_data = row[5];
-        bool outdated = row[6] != 0.0f;
-        const bool repeat = __float_as_uint(row[7]) == step + 1u;  // stamp = step + 1 (0 = never)
-        const bool was_reset = fill_all || Bf.reset_buf[e];
-        if (!repeat) {
-            for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
-            outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
-            if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
-                ts = 0.0f; last = 0.0f; outdated = true;
-                if (Bf.scan_drift_feed) {
-                    drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
-                } else {
-                    const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
-                    drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
-                    dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
-                    drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
-                }
-            }
-        } else {
-            outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
-        }
-        float keep = 0.0f;
-        if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
-            pz_data = pz + drz;
-            last = ts;
-            float ts2 = ts;  // will this env's sensor be outdated at the next step?  If not, its hit heights must survive this one
-            for (int k = 0; k < P.scan_substeps; ++k) ts2 = ts2 + P.scan_dt;
-            keep = (keep_all_hits || !(ts2 - last + 1.0e-6f >= P.scan_period)) ? 1.0f : 0.0f;
-        }
-        if (threadIdx.x == 0) {
-            float4* o = reinterpret_cast<float4*>(row);
-            o[0] = make_float4(ts, last, drx, dry);
-            o[1] = make_float4(drz, pz_data, 0.0f, __uint_as_float(step + 1u));
-            s_scan[0] = outdated ? 1.0f : 0.0f; s_scan[1] = keep; s_scan[2] = drx; s_scan[3] = dry; s_scan[4] = pz_data;
-        }
-    }
-    __syncthreads();
-    cast = s_scan[0] != 0.0f;
-    cache_z = s_scan[1] != 0.0f;
-    if (cast) { px += s_scan[2]; py += s_scan[3]; }
-    pz = s_scan[4];  // data.pos_w z of the last update (height_scan reads sensor.data.pos_w, observations.py:172)
-}
-
 // One ray of the scanner: RayCaster._update_buffers_impl (ray_caster.py:242-260) -> hit height (+inf on a miss, ops.py:70)
 template <bool GENERAL_RAYS>
 IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __restrict__ es, const float* __restrict__ ray_local, int j,
@@ -854,19 +866,32 @@ IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __rest
 }
 
 // The observation kernel of a LEAN plan with a height scanner (one observation group, no modifier programs, no history windows: every
-// rough-terrain task config of BASELINE.json).  Workgroup = env: RW ray waves + one column wave, side by side, no barrier between
-// them.  A ray lane casts ray j and finishes ITS height_scan column on the spot -- the term's offset / noise / clip / scale are the
-// same for all R columns, so they travel in scalar registers (one record, scalar loads) instead of a 16-word column record per lane;
-// the column wave fills the env's other columns (base velocity, joints, actions ...) meanwhile.  59 VGPRs: eight waves per SIMD.
+// rough-terrain task config of BASELINE.json).  Workgroup = ONE WAVE: wave `role` of env e casts rays 64*role .. 64*role+63 and finishes
+// THEIR height_scan columns on the spot -- the term's offset / noise / clip / scale are the same for all R columns, so they travel in
+// scalar registers (one record, scalar loads) instead of a 16-word column record per lane; the env's last wave fills its other columns
+// (base velocity, joints, actions ...).  No LDS, no barrier: the sensor's per-step decision (cast? where? keep the hits?) sits in the
+// frame row, put there by the kernel that produced the row.  Single-wave workgroups because what bounds this kernel is how fast the
+// chip re-fills wave slots after the first residency round (tools/trace_kobs.py): a one-wave workgroup fits any free slot, a four-wave
+// one needs four on one CU.
 template <bool GENERAL_RAYS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(64)
 k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
            const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G,
-           int scan_rec, int ray_threads) {
-    const int64_t e = blockIdx.x;
-    if (e == N) {  // the extra workgroup: the step tail k_term_rew deferred (its partials are complete: kernel boundary)
-        step_tail(P, N, Bf, sc, tail_G);
+           int tail_parts, int scan_rec, int waves_per_env) {
+    if ((int)blockIdx.x < tail_parts) {  // extra workgroups, first in the grid: the step tail k_term_rew deferred (kernel boundary = its partials are complete)
+        step_tail(P, N, Bf, sc, tail_G, (int)blockIdx.x, tail_parts);
         return;
+    }
+    const unsigned b = blockIdx.x - (unsigned)tail_parts;
+    int64_t e;
+    int role;
+    if (waves_per_env > 0) {
+        e = b / (unsigned)waves_per_env;
+        role = (int)(b - (unsigned)e * (unsigned)waves_per_env);
+    } else {  // role-major order (the host's choice for small grids)
+        waves_per_env = -waves_per_env;
+        role = (int)(b / (unsigned)N);
+        e = b - (unsigned)role * (unsigned)N;
     }
     const int32_t* __restrict__ W = P.w;
     const uint32_t step = (uint32_t)Bf.counters[2];
@@ -874,14 +899,12 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
     const bool keep_all_hits = (corrupt & 8) != 0;
     corrupt &= 1;
     const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
-    float px = es[9], py = es[10], pz = es[11];
-    bool cast = true, cache_z = false;
     const int D = P.gD[0];
-    // (Casting the rays BEFORE the scanner row is consulted -- legal without a drift range, and one round trip less on paper -- was
-    // measured: 23.6 us against 21.3; the barrier first, then rays and columns side by side, is the faster order.)
-    if (P.scan_stateful) scanner_update(P, Bf, e, step, fill_all, keep_all_hits, seed, px, py, pz, cast, cache_z);
-    if ((int)threadIdx.x < ray_threads) {
+    if (role < waves_per_env - 1) {
         // height_scan (observations.py:165-173): sensor.data.pos_w z - hit z - offset, then noise -> clip -> scale (observation_manager.py:313-318)
+        const int sflags = (int)es[20];
+        const bool cast = (sflags & 1) != 0, cache_z = P.scan_stateful && ((sflags & 2) || keep_all_hits);
+        const float px = es[21], py = es[22], pz = es[23];
         const int32_t* r = W + P.obs_off + scan_rec * IMX_REC_WORDS;
         const int out = r[IMX_R_OUT], flags = r[IMX_R_FLAGS];
         const float off = f_of(r[IMX_R_P0]), nlo = f_of(r[IMX_R_NOISE_LO]), nhi = f_of(r[IMX_R_NOISE_HI]);
@@ -889,31 +912,28 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         const bool noisy = (corrupt & P.gcorrupt) && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS));
         const float* __restrict__ ray_local = reinterpret_cast<const float*>(W + P.ray_off);
         const float yw = es[16], yz = es[17];
-        // one ray per lane (the host sizes ray_threads >= R)
-        const int j = (int)threadIdx.x;
-        const bool has = j < P.R;
-        float hz = 0.0f;
-        if (cast && has) hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
-        if (has) {
-            if (cast) {
-                if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
-            } else {
-                hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
-            }
-            float v = pz - hz - off;
-            const int c = out + j;
-            if (noisy) {
-                const float u = noise_u ? noise_u[e * P.D + c] : uniform01(seed, step, (uint64_t)e * P.D + c);
-                const float nz = u * (nhi - nlo) + nlo;  // noise_model.py:62-66
-                v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
-            }
-            if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);
-            if (flags & IMX_F_SCALE) v = v * scale;
-            Bf.obs[e * D + c] = v;
+        const int j = role * 64 + (int)threadIdx.x;  // one ray per lane
+        if (j >= P.R) return;
+        float hz;
+        if (cast) {
+            hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
+            if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
+        } else {
+            hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
         }
+        float v = pz - hz - off;
+        const int c = out + j;
+        if (noisy) {
+            const float u = noise_u ? noise_u[e * P.D + c] : uniform01(seed, step, (uint64_t)e * P.D + c);
+            const float nz = u * (nhi - nlo) + nlo;  // noise_model.py:62-66
+            v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
+        }
+        if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);
+        if (flags & IMX_F_SCALE) v = v * scale;
+        Bf.obs[e * D + c] = v;
     } else {
-        const int lanes = (int)blockDim.x - ray_threads;
-        for (int i = P.n_ray_cols + ((int)threadIdx.x - ray_threads); i < P.DC; i += lanes) {  // xcol lists the ray columns first
+        if (e == 0 && threadIdx.x == 0) Bf.counters[3] = (int32_t)step;  // the shadow the next step kernel counts on from
+        for (int i = P.n_ray_cols + (int)threadIdx.x; i < P.DC; i += 64) {  // xcol lists the ray columns first
             const XCol x = load_xcol(W, P.xcol_off, i);
             obs_finish<true>(P, Bf, x, i, obs_plain_value(P, S, Bf, es, e, x), e, corrupt, fill_all, noise_u, seed, step);
         }
@@ -923,14 +943,15 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
 template <bool GENERAL_RAYS, bool LEAN>
 __global__ void __launch_bounds__(256)
 k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
-      const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G) {
+      const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G,
+      int tail_parts) {
     // One workgroup per env.  (A resident grid walking the envs -- sized to what the chip holds at once -- was measured and dropped:
     // the loop costs 13 more VGPRs, i.e. one wave per SIMD less, and three uneven rounds: 35 us against 29.)
-    const int64_t e = blockIdx.x;
-    if (e == N) {  // the extra workgroup: the step tail k_term_rew deferred (its partials are complete: kernel boundary)
-        step_tail(P, N, Bf, sc, tail_G);
+    if ((int)blockIdx.x < tail_parts) {  // extra workgroups, first in the grid: the step tail k_term_rew deferred (kernel boundary = its partials are complete)
+        step_tail(P, N, Bf, sc, tail_G, (int)blockIdx.x, tail_parts);
         return;
     }
+    const int64_t e = blockIdx.x - (unsigned)tail_parts;
     const int32_t* __restrict__ W = P.w;
     const uint32_t step = (uint32_t)Bf.counters[2];
     const bool fill_all = (corrupt & 2) != 0;
@@ -938,20 +959,13 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
     corrupt &= 1;
     extern __shared__ float s_hz[];  // R hit heights of this env
     const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
-    float pz = es[11];
     const float yw = es[16], yz = es[17];
-    float px = es[9], py = es[10];
+    // the sensor's decision for this step (scanner_step, made where the frame row was produced): cast?  keep the hits?  from where?
+    const int sflags = (int)es[20];
+    const bool cast = (sflags & 1) != 0, cache_z = P.scan_stateful && ((sflags & 2) || keep_all_hits);
+    const float px = es[21], py = es[22], pz = es[23];
 #ifdef IMX_TRACE
-    uint64_t trace_tp = 0;
-#endif
-    bool cast = true, cache_z = false;
-    if (P.scan_stateful) {
-        scanner_update(P, Bf, e, step, fill_all, keep_all_hits, seed, px, py, pz, cast, cache_z);
-#ifdef IMX_TRACE
-        trace_tp = wall_clock64();
-#endif
-    }
-#ifdef IMX_TRACE
+    const uint64_t trace_tp = 0;
     const uint64_t trace_t0 = wall_clock64();
     uint64_t trace_t1 = 0, trace_t2 = 0;
 #endif
@@ -979,6 +993,7 @@ k_obs(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const 
         trace_t2 = wall_clock64();
 #endif
     }
+    if (e == 0 && threadIdx.x == 0) Bf.counters[3] = (int32_t)step;  // the shadow the next step kernel counts on from
     // -- phase B: the observation columns (ObservationManager.compute_group, observation_manager.py:260-335)
     for (int i = threadIdx.x; i < P.DC; i += blockDim.x) {
         const XCol x = load_xcol(W, P.xcol_off, i);
@@ -1120,6 +1135,8 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
         }
     }
     if (plan->CMD > 0 && !st->command) IMX_FAIL("command tensor missing");
+    IMX_REQUIRE(!plan->scan_stateful || !st->root_pos_w || bf->scan_state,
+                "imx_terminations_rewards: the height scanner has an update period / drift range: scan_state (N,8) is required");
     const int G = step_group_size(N);
     const unsigned grid = (unsigned)((N + G - 1) / G);
     StepScratch sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
@@ -1182,41 +1199,51 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
     if (!(enable_corruption & 4))  // bit 2: imx_terminations_rewards ran on this very state and left the frame table behind
-        hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, frame);
+        hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, frame, (enable_corruption >> 1) & 1);
     // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
     const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
     // bit 4: finish the step tail imx_terminations_rewards (flags bit 0) left to this call -- one extra workgroup
     const bool tail = (enable_corruption & 16) != 0;
     StepScratch sc{};
-    int tail_G = 0;
+    int tail_G = 0, tail_parts = 0;
     if (tail) {
         IMX_REQUIRE(bf->reset_env_ids && bf->log_out, "imx_observations: finishing the step tail needs reset_env_ids and log_out");
         sc = carve(bf->scratch, N, plan->nrew_all > 0 ? plan->nrew_all : 1, plan->nterm > 0 ? plan->nterm : 1);
         tail_G = step_group_size(N);
     }
     const size_t lds = (size_t)(pv.R > 0 ? pv.R : 1) * 4;
-    const unsigned grid = (unsigned)N + (tail ? 1u : 0u);
+    const int nlog = plan->nrew_all + plan->nterm;
     // the lean variant: one group, no modifier programs, no history windows (DC == D also rules out twin scan columns)
     bool lean = plan->ngroups == 1 && plan->MS == 0 && plan->DC == plan->D && plan->DX == plan->DC;
     for (int k = 0; k < plan->nobs && lean; ++k) lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & IMX_F_MODIFIERS);
 #define IMX_LAUNCH_OBS(G, L)                                                                                                     \
     hipLaunchKernelGGL((k_obs<G, L>), dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed, \
-                       enable_corruption, ray_hits_out_d, sc, tail_G)
+                       enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts)
     int scan_rec = -1;
     for (int k = 0; k < plan->nobs; ++k)
         if (w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) scan_rec = k;
     if (lean && scan_rec >= 0 && pv.R > 0 && pv.R <= 64 * 15) {
-        // ray waves (at most 4: a lane then takes several rays) + one wave for the other columns
-        const int rw = (pv.R + 63) / 64;  // one ray per lane
-        const int threads = 64 * (rw + 1);
+        // one single-wave workgroup per 64 rays + one for the env's other columns
+        const int wpe = (pv.R + 63) / 64 + 1;
+        IMX_REQUIRE((uint64_t)N * wpe + 1 < (1ull << 31), "imx_observations: %lld envs x %d waves exceed the grid", (long long)N, wpe);
+        if (tail) tail_parts = 1 + (nlog < 16 ? nlog : 16);  // one wave orders the reset ids, one per log entry (<= 16)
+        // Up to ~2 residency rounds the waves go out role by role (all envs' first 64 rays, ..., the short column waves last: a
+        // shorter drain, 17.2 us against 18.6 at 4096 envs); beyond that env by env (an env's rays share mesh lines: 173 us against
+        // 191 at 65536 envs).
+        const bool role_major = N <= 8192;
+        const unsigned lgrid = (unsigned)(N * wpe) + (unsigned)tail_parts;
         if (vertical)
-            hipLaunchKernelGGL(k_obs_lean<false>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d,
-                               seed, enable_corruption, ray_hits_out_d, sc, tail_G, scan_rec, 64 * rw);
+            hipLaunchKernelGGL(k_obs_lean<false>, dim3(lgrid), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed,
+                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe);
         else
-            hipLaunchKernelGGL(k_obs_lean<true>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d,
-                               seed, enable_corruption, ray_hits_out_d, sc, tail_G, scan_rec, 64 * rw);
-    } else if (vertical) { if (lean) IMX_LAUNCH_OBS(false, true); else IMX_LAUNCH_OBS(false, false); }
-    else { if (lean) IMX_LAUNCH_OBS(true, true); else IMX_LAUNCH_OBS(true, false); }
+            hipLaunchKernelGGL(k_obs_lean<true>, dim3(lgrid), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed,
+                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe);
+    } else {
+        if (tail) tail_parts = 1 + ((nlog < 16 ? nlog : 16) * 64 + bs - 1) / bs;
+        const unsigned grid = (unsigned)N + (unsigned)tail_parts;
+        if (vertical) { if (lean) IMX_LAUNCH_OBS(false, true); else IMX_LAUNCH_OBS(false, false); }
+        else { if (lean) IMX_LAUNCH_OBS(true, true); else IMX_LAUNCH_OBS(true, false); }
+    }
 #undef IMX_LAUNCH_OBS
     IMX_HIP(hipGetLastError());
     return 0;

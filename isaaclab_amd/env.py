@@ -496,7 +496,7 @@ class ManagerBasedRLEnv:
         self.max_episode_length_s = plan.max_episode_length_s
         self.common_step_counter = 0
         self._sim_step_counter = 0
-        self.noise_seed = int(noise_seed)
+        self._noise_seed = int(noise_seed)  # the property below also leaves it in counters[4..5] (sensor-drift stream of the step kernel)
         self.clip_actions: float | None = None  # set by RslRlVecEnvWrapper: fused into imx_action_process
         self.extras: dict = {}
 
@@ -513,6 +513,7 @@ class ManagerBasedRLEnv:
         self.reset_terminated, self.reset_time_outs, self.reset_buf = (z(N, dtype=torch.bool) for _ in range(3))
         self._reset_env_ids = z(N, dtype=torch.long)
         self._counters = z(8, dtype=torch.int32)
+        self.noise_seed = self._noise_seed
         self._log_out = z(K + NT + 1)
         self._obs_groups = [z(N, max(g.dim, 1)) for g in plan.obs_groups]  # one (N, D_g) tensor per observation group
         self._obs = self._obs_groups[0]
@@ -624,6 +625,19 @@ class ManagerBasedRLEnv:
     def episode_length_buf(self, value: torch.Tensor):
         # RSL-RL's init_at_random_ep_len assigns a new tensor (vecenv_wrapper.py:144-156); keep the pointer stable
         self._episode_length_buf.copy_(value.to(self.device, torch.long))
+
+    @property
+    def noise_seed(self) -> int:
+        """Seed of the in-kernel generators (observation noise: an ``imx_observations`` argument; sensor drift: ``counters[4..5]``)."""
+        return self._noise_seed
+
+    @noise_seed.setter
+    def noise_seed(self, value: int):
+        self._noise_seed = int(value)
+        if getattr(self, "_counters", None) is not None:
+            lo, hi = self._noise_seed & 0xFFFFFFFF, (self._noise_seed >> 32) & 0xFFFFFFFF
+            words = torch.tensor([lo, hi], dtype=torch.int64).to(torch.int32)  # two's-complement wrap
+            self._counters[4:6].copy_(words)
 
     @property
     def reset_env_ids(self) -> torch.Tensor:
@@ -832,6 +846,7 @@ class ManagerBasedRLEnv:
             self._eval_external("rew")
         # flag 1: the end of the step (ordered reset ids, reset count, Episode_* log) is finished by an extra workgroup of the
         # observation kernel below -- same stream, kernel boundary in between -- instead of a fence + ticket in this launch
+        self._bufs.scan_drift_feed = _lib.ptr(self._scan_drift_feed)  # the step kernel advances the sensor clock (resets draw a drift)
         check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
                                                  ctypes.byref(self._bufs), 1 if self.defer_step_tail else 0, _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
