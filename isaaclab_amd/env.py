@@ -200,7 +200,15 @@ class ObservationManager:
 
     @property
     def group_obs_dim(self):
-        return {g.name: (g.dim,) for g in self._groups}
+        """observation_manager.py:85-101: the concatenated shape -- the reference SUMS the term shapes element-wise, so terms that keep
+        their history axis add up in that axis too, (H, d1) + (H, d2) -> (2H, d1 + d2); mirrored -- or the list of term shapes."""
+        out = {}
+        for g in self._groups:
+            if g.concatenate:
+                out[g.name] = tuple(int(sum(d[i] for d in g.term_dims)) for i in range(len(g.term_dims[0])))
+            else:
+                out[g.name] = list(g.term_dims)
+        return out
 
     @property
     def group_obs_term_dim(self):
@@ -208,19 +216,36 @@ class ObservationManager:
 
     @property
     def group_obs_concatenate(self):
-        return {g.name: True for g in self._groups}
+        return {g.name: g.concatenate for g in self._groups}
+
+    def shaped(self) -> dict:
+        """The groups as the reference hands them out (observation_manager.py:320-335).  A concatenated group of one-dimensional terms
+        IS its fused row; a group of terms that keep their history axis is the concatenation of the (N, H, d) windows along the last
+        axis; ``concatenate_terms=False`` gives the dict of terms -- views of the row the kernel filled, no extra launch."""
+        out = {}
+        for g, row in zip(self._groups, self._env._obs_groups):
+            if g.is_flat:
+                out[g.name] = row
+                continue
+            terms, off = {}, 0
+            for t, shape, w in zip(g.terms, g.term_dims, g.term_widths):
+                v = row[:, off:off + w]
+                terms[t.name] = v.unflatten(1, shape) if len(shape) > 1 else v
+                off += w
+            out[g.name] = torch.cat(list(terms.values()), dim=-1) if g.concatenate else terms
+        return out
 
     def compute(self) -> dict:
         """observation_manager.py:238-258: every group (one launch fills them all)."""
         self._env._compute_observations()
-        return dict(self._env.obs_buf)
+        return self.shaped()
 
     def compute_group(self, group_name: str):
         if group_name not in self._env.obs_buf:  # observation_manager.py:293-297
             raise ValueError(f"Unable to find the group '{group_name}' in the observation manager."
                              f" Available groups are: {list(self._env.obs_buf)}")
         self._env._compute_observations()
-        return self._env.obs_buf[group_name]
+        return self.shaped()[group_name]
 
     def reset(self, env_ids=None) -> dict:
         return {}
@@ -672,9 +697,21 @@ class ManagerBasedRLEnv:
             box = lambda shape: types.SimpleNamespace(low=-np.inf, high=np.inf, shape=tuple(shape), dtype=np.float32)  # noqa: E731
             dct = dict
         N = self.num_envs
-        self.single_observation_space = dct({g.name: box((g.dim,)) for g in self.plan.obs_groups})
+        om = self.observation_manager
+
+        def spaces(batch: tuple):  # a Box per concatenated group (its group_obs_dim), a Dict of term Boxes otherwise
+            out = {}
+            for gname, tnames in om.active_terms.items():
+                gdim = om.group_obs_dim[gname]
+                if om.group_obs_concatenate[gname]:
+                    out[gname] = box(batch + tuple(gdim))
+                else:
+                    out[gname] = dct({t: box(batch + tuple(d)) for t, d in zip(tnames, gdim)})
+            return dct(out)
+
+        self.single_observation_space = spaces(())
         self.single_action_space = box((self.plan.action_dim,))
-        self.observation_space = dct({g.name: box((N, g.dim)) for g in self.plan.obs_groups})
+        self.observation_space = spaces((N,))
         self.action_space = box((N, self.plan.action_dim))
 
     def close(self):
@@ -827,7 +864,7 @@ class ManagerBasedRLEnv:
             self.reset_buf.zero_()
             self.reset_buf[ids] = True
             self._compute_observations()
-        return dict(self.obs_buf), self.extras
+        return self.observation_manager.shaped(), self.extras
 
     def step(self, action: torch.Tensor):
         """ManagerBasedRLEnv.step (manager_based_rl_env.py:153-242)."""
@@ -862,7 +899,7 @@ class ManagerBasedRLEnv:
         # -- observations on the post-reset state (one kernel, ray-cast fused); imx_terminations_rewards left the frame table of
         #    this state snapshot behind (the feed's root state is not rewritten by the reset events: they go to sim_writes)
         self._compute_observations(frame_current=True, finish_step_tail=self.defer_step_tail)
-        return dict(self.obs_buf), self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+        return self.observation_manager.shaped(), self._reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     @property
     def cfg_decimation(self) -> int:

@@ -150,7 +150,14 @@ class ObsGroup:
     num_records: int = 0
     dim: int = 0
     terms: list = dataclasses.field(default_factory=list)
-    term_dims: list = dataclasses.field(default_factory=list)
+    term_dims: list = dataclasses.field(default_factory=list)    # the reference's group_obs_term_dim: (d,), (H*d,) or (H, d) per term
+    term_widths: list = dataclasses.field(default_factory=list)  # columns of each term in the fused row (history windows flattened, oldest first)
+    concatenate: bool = True                                     # ObservationGroupCfg.concatenate_terms
+
+    @property
+    def is_flat(self) -> bool:
+        """The group IS its fused row: concatenated, every term one-dimensional."""
+        return self.concatenate and all(len(d) == 1 for d in self.term_dims)
 
 
 class _Blob:
@@ -517,9 +524,10 @@ class PlanCompiler:
         group_keys = ("concatenate_terms", "enable_corruption", "history_length", "flatten_history_dim")
         for gi, gname in enumerate(group_names):
             gcfg = obs_groups_cfg[gname]
-            if not gcfg.get("concatenate_terms", True):
-                raise NotImplementedError(f"observation group '{gname}': non-concatenated groups are not on the fused path")
-            grp = ObsGroup(name=gname, enable_corruption=bool(gcfg.get("enable_corruption", False)), first_record=len(obs_recs))
+            # concatenate_terms=False / flatten_history_dim=False change the SHAPE the manager hands out, not what is computed: the
+            # kernel fills the same fused row, ObservationManager returns views of it (env.py)
+            grp = ObsGroup(name=gname, enable_corruption=bool(gcfg.get("enable_corruption", False)), first_record=len(obs_recs),
+                           concatenate=bool(gcfg.get("concatenate_terms", True)))
             D = 0
             for name, tcfg in gcfg.items():
                 if name in group_keys or tcfg is None or not isinstance(tcfg, dict) or "func" not in tcfg:
@@ -531,8 +539,6 @@ class PlanCompiler:
                 gh = gcfg.get("history_length")
                 hist = int(gh if gh is not None else (tcfg.get("history_length") or 0))
                 flat = gcfg.get("flatten_history_dim", True) if gh is not None else tcfg.get("flatten_history_dim", True)
-                if hist > 0 and not flat:
-                    raise NotImplementedError(f"observation term '{name}': un-flattened history is not on the fused path")
                 rec = dict(out=D, weight=int(gi))
                 flags = 0
                 known = True  # the term FUNCTION is one of the fused ops (else: evaluated by calling the Python term, IMX_O_EXTERNAL)
@@ -645,8 +651,13 @@ class PlanCompiler:
                 rec.update(dim=dim, flags=flags, aux1=hist)
                 obs_recs.append(_rec(**rec))
                 grp.terms.append(Term(name, fn, rec["op"], p, external=None if known else tcfg["func"], dim=width, py_modifiers=py_mods))
-                grp.term_dims.append((width,))
+                grp.term_dims.append((hist, dim) if hist > 0 and not flat else (width,))
+                grp.term_widths.append(width)
                 D += width
+            if grp.concatenate and len({len(d) for d in grp.term_dims}) > 1:  # observation_manager.py:89-99
+                raise RuntimeError(f"Unable to concatenate observation terms in group '{gname}'. The shapes of the terms are: {grp.term_dims}."
+                                   " Please ensure that the shapes are compatible for concatenation. Otherwise, set 'concatenate_terms' to False"
+                                   " in the group configuration.")
             grp.dim = D
             grp.num_records = len(obs_recs) - grp.first_record
             groups.append(grp)

@@ -14,6 +14,11 @@ import torch
 from ..env import ManagerBasedRLEnv
 
 
+def _own(obs):
+    """Copies of the env's observation buffers (it rewrites them in place at the next step); groups may be dicts of terms."""
+    return {k: _own(v) if isinstance(v, dict) else v.clone() for k, v in obs.items()}
+
+
 class RslRlVecEnvWrapper:
     def __init__(self, env: ManagerBasedRLEnv, clip_actions: float | None = None):
         if not isinstance(env.unwrapped, ManagerBasedRLEnv):
@@ -56,7 +61,7 @@ class RslRlVecEnvWrapper:
         return self.env.unwrapped
 
     def get_observations(self) -> tuple[torch.Tensor, dict]:
-        obs_dict = {k: v.clone() for k, v in self.unwrapped.observation_manager.compute().items()}
+        obs_dict = _own(self.unwrapped.observation_manager.compute())
         return obs_dict["policy"], {"observations": obs_dict}
 
     @property
@@ -72,14 +77,14 @@ class RslRlVecEnvWrapper:
 
     def reset(self) -> tuple[torch.Tensor, dict]:
         obs_dict, _ = self.env.reset()
-        obs_dict = {k: v.clone() for k, v in obs_dict.items()}
+        obs_dict = _own(obs_dict)
         return obs_dict["policy"], {"observations": obs_dict}
 
     def step(self, actions: torch.Tensor):
         # the clamp of vecenv_wrapper.py:173-174 happens inside imx_action_process (env.clip_actions)
         obs_dict, rew, terminated, truncated, extras = self.env.step(actions)
         dones = (terminated | truncated).to(dtype=torch.long)
-        obs_dict = {k: v.clone() for k, v in obs_dict.items()}
+        obs_dict = _own(obs_dict)
         obs = obs_dict["policy"]
         extras["observations"] = obs_dict
         if not self.unwrapped.is_finite_horizon:

@@ -331,8 +331,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
     A = env.action_manager.total_action_dim
     om = env.observation_manager
     group_names = list(om.group_obs_dim)
-    D0 = om.group_obs_dim[group_names[0]][0]
-    D = sum(om.group_obs_dim[g][0] for g in group_names)
+
+    def flat_width(g):  # columns of the group in the fused row: every term flattened (history windows oldest first), side by side
+        return int(sum(int(np.prod(d)) for d in om.group_obs_term_dim[g]))
+
+    D0 = flat_width(group_names[0])
+    D = sum(flat_width(g) for g in group_names)
     gen = torch.Generator().manual_seed(seed + 1000)
     rec: dict[str, np.ndarray] = {}
 
@@ -340,7 +344,11 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         rec[name] = t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
     meta = dict(task=task, robot=robot.name, num_envs=N, steps=steps, seed=seed, action_dim=int(A), obs_dim=int(D0), obs_dim_total=int(D),
-                obs_groups=group_names, obs_group_dims=[int(om.group_obs_dim[g][0]) for g in group_names],
+                obs_groups=group_names, obs_group_dims=[flat_width(g) for g in group_names],
+                obs_group_shapes={g: (_jsonable(om.group_obs_dim[g])) for g in group_names},
+                obs_group_term_shapes={g: [[int(x) for x in d] for d in om.group_obs_term_dim[g]] for g in group_names},
+                obs_group_terms={g: list(om.active_terms[g]) for g in group_names},
+                obs_group_concatenate={g: bool(om.group_obs_concatenate[g]) for g in group_names},
                 step_dt=env.step_dt, max_episode_length=env.max_episode_length,
                 max_episode_length_s=env.max_episode_length_s, gravity_dir=feed.gravity_dir,
                 reward_terms=env.reward_manager.active_terms, termination_terms=env.termination_manager.active_terms,
@@ -368,7 +376,7 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         # order ObservationManager.compute walks them)
         noisy_offsets, base = [], 0
         for gname in group_names:
-            dims = [d[0] for d in om.group_obs_term_dim[gname]]
+            dims = [int(np.prod(d)) for d in om.group_obs_term_dim[gname]]
             cfgs = om._group_obs_term_cfgs[gname]
             offs = np.concatenate([[0], np.cumsum(dims)])
             noisy_offsets += [base + int(offs[i]) for i, c in enumerate(cfgs) if c.noise]
@@ -387,7 +395,11 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
         obs = all_obs[group_names[0]]
         put(f"{tag}/obs", obs)
         for gname in group_names[1:]:
-            put(f"{tag}/obs/{gname}", all_obs[gname])
+            if isinstance(all_obs[gname], dict):  # concatenate_terms = False: a dict of term tensors
+                for tname, tv in all_obs[gname].items():
+                    put(f"{tag}/obs/{gname}/{tname}", tv)
+            else:
+                put(f"{tag}/obs/{gname}", all_obs[gname])
         if scanner is not None:  # what the lazy refresh inside compute() left in the sensor
             put(f"{tag}/sensor_pos_w", scanner._data.pos_w)
             put(f"{tag}/ray_hits_w", scanner._data.ray_hits_w)
@@ -665,6 +677,33 @@ def main():
         hist_cfg.observations.policy.history_length = 3
         hist_cfg.observations.policy.flatten_history_dim = True
         run_task("Isaac-Velocity-Flat-Anymal-C-v0-hist3", hist_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=105)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0-shapes"):
+        # the group shapes besides the flat concatenation (observation_manager.py:320-335): a group returned as a dict of terms
+        # (concatenate_terms=False) holding an un-flattened (N, H, d) history term, a flattened one and a plain one; and a concatenated
+        # group whose terms keep their history axis (group-level history_length, flatten_history_dim=False): (N, H, sum d)
+        import isaaclab.envs.mdp as mdp
+        from isaaclab.managers import ObservationGroupCfg, ObservationTermCfg as Obs
+        from isaaclab.utils.noise import AdditiveUniformNoiseCfg as Unoise
+
+        shp_cfg = AnymalCFlatEnvCfg()
+        terms = ObservationGroupCfg()
+        terms.concatenate_terms = False
+        terms.enable_corruption = True
+        terms.base_lin_vel = Obs(func=mdp.base_lin_vel, noise=Unoise(n_min=-0.1, n_max=0.1), history_length=2, flatten_history_dim=False)
+        terms.joint_pos = Obs(func=mdp.joint_pos_rel, noise=Unoise(n_min=-0.01, n_max=0.01))
+        terms.actions = Obs(func=mdp.last_action, history_length=3)
+        terms.joint_vel = Obs(func=mdp.joint_vel_rel, scale=0.05, clip=(-1.0, 1.0), history_length=2, flatten_history_dim=False)
+        shp_cfg.observations.terms = terms
+        stack = ObservationGroupCfg()
+        stack.concatenate_terms = True
+        stack.enable_corruption = False
+        stack.history_length = 2
+        stack.flatten_history_dim = False
+        stack.base_ang_vel = Obs(func=mdp.base_ang_vel)
+        stack.projected_gravity = Obs(func=mdp.projected_gravity)
+        stack.velocity_commands = Obs(func=mdp.generated_commands, params={"command_name": "base_velocity"})
+        shp_cfg.observations.stack = stack
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0-shapes", shp_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=108)
     if want("Isaac-Velocity-Flat-Anymal-C-v0-mod"):
         # observation modifiers (ObservationTermCfg.modifiers; utils/modifiers/modifier.py): stateless chain, IIR/FIR filter,
         # integrator -- on the flat task, 6 steps so that filter/integrator state and its reset are exercised

@@ -68,6 +68,21 @@ def assert_close(a, b, tol=FLOAT_TOL, what=""):
 KITCHEN = "Isaac-Velocity-Rough-Anymal-C-v0-kitchen"  # every remaining isaaclab.envs.mdp op + a "critic" group + the scanner as a SensorBase
 
 
+SHAPES = "Isaac-Velocity-Flat-Anymal-C-v0-shapes"  # a dict-of-terms group, un-flattened history terms, a (N, H, sum d) group
+
+
+def assert_groups_close(got: dict, g: "Golden", tag: str, tol: float):
+    """Every observation group of a fixture step, in the shape the reference's ObservationManager returned it (tensor or dict of terms)."""
+    for gname in g.meta["obs_groups"]:
+        key = f"{tag}/obs" if gname == g.meta["obs_groups"][0] else f"{tag}/obs/{gname}"
+        if g.meta.get("obs_group_concatenate", {}).get(gname, True):
+            assert_close(got[gname], g.t(key), tol, f"{tag} group {gname}")
+        else:
+            assert isinstance(got[gname], dict) and list(got[gname]) == g.meta["obs_group_terms"][gname], gname
+            for tname in g.meta["obs_group_terms"][gname]:
+                assert_close(got[gname][tname], g.t(f"{key}/{tname}"), tol, f"{tag} group {gname} term {tname}")
+
+
 def set_reward_weight(cfg_env: dict, term: str, weight: float):
     """What the reference's ``modify_reward_weight`` curriculum term does to the manager's term cfg (envs/mdp/curriculums.py:20-37)."""
     cfg_env["rewards"][term]["weight"] = weight

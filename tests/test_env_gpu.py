@@ -69,6 +69,37 @@ def test_env_step_matches_reference_goldens(task, tail):
     env.close()
 
 
+def test_group_shapes_match_reference():
+    """The other shapes ObservationManager hands out (observation_manager.py:320-335) -- a dict-of-terms group, un-flattened (N, H, d)
+    history terms, a concatenated (N, H, sum d) group -- are views of the row the one fused launch fills; fixture from the real manager,
+    5 steps with resets (history windows of reset envs refill with their first value)."""
+    from _util import SHAPES, assert_groups_close
+
+    g = Golden(SHAPES)
+    env = make_env(g)
+    om = env.observation_manager
+    assert om.group_obs_concatenate == g.meta["obs_group_concatenate"]
+    assert {k: [list(d) for d in v] for k, v in om.group_obs_term_dim.items()} == g.meta["obs_group_term_shapes"]
+    shapes = {k: ([list(d) for d in v] if isinstance(v, list) else list(v)) for k, v in om.group_obs_dim.items()}
+    assert shapes == g.meta["obs_group_shapes"]  # incl. the reference's element-wise sum for the stacked group: (6, 9)
+    assert env.single_observation_space["terms"]["base_lin_vel"].shape == (2, 3) and env.observation_space["terms"]["actions"].shape == (g.N, 36)
+    env._noise_u = g.t("reset/noise_u").cuda()
+    obs_dict, _ = env.reset()
+    assert_groups_close(obs_dict, g, "reset", FLOAT_TOL)
+    env.episode_length_buf = g.t("reset/episode_length_buf")
+    for k in range(g.steps):
+        tag = f"step{k}"
+        env._noise_u.copy_(g.t(f"{tag}/noise_u"))
+        obs_dict, rew, terminated, time_outs, extras = env.step(g.t(f"{tag}/action").cuda())
+        assert torch.equal(env.reset_env_ids.cpu(), g.t(f"{tag}/reset_env_ids"))
+        assert_close(rew, g.t(f"{tag}/reward"), FLOAT_TOL, "reward")
+        assert_groups_close(obs_dict, g, tag, FLOAT_TOL)
+    assert obs_dict["stack"].shape == (g.N, 2, 9) and obs_dict["terms"]["joint_vel"].shape == (g.N, 2, 12)
+    with pytest.raises(ValueError):
+        om.compute_group("nope")
+    env.close()
+
+
 def test_wrapper_surface_and_time_outs():
     from isaaclab_amd.rsl_rl import RslRlVecEnvWrapper
 

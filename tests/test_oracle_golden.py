@@ -130,6 +130,28 @@ def test_rough_fixture_mesh_is_the_generator_mesh_at_head(task):
     assert len(t) < 2 * 81 * 81 * 6, "expected a mixed mesh, not six all-height-field tiles"
 
 
+def test_oracle_matches_reference_group_shapes():
+    """ObservationManager's other group shapes (observation_manager.py:320-335), fixture from the real manager: a group handed out as
+    a dict of terms (concatenate_terms=False) with un-flattened (N, H, d) history terms next to flattened and plain ones, and a
+    concatenated group whose terms keep their history axis, (N, H, sum d)."""
+    from _util import SHAPES, assert_groups_close
+
+    g = Golden(SHAPES)
+    assert g.meta["obs_group_concatenate"] == {"policy": True, "terms": False, "stack": True}
+    feed = g.feed()
+    env = make_oracle(g, feed)
+    assert_groups_close(env.compute_observation_groups(g.t("reset/noise_u")), g, "reset", 1e-6)
+    env.episode_length_buf[:] = g.t("reset/episode_length_buf")
+    for k in range(g.steps):
+        tag = f"step{k}"
+        env.process_action(g.t(f"{tag}/action"))
+        feed.advance()
+        out = env.post_physics_step(g.t(f"{tag}/noise_u"))
+        assert torch.equal(out["reset_env_ids"], g.t(f"{tag}/reset_env_ids"))
+        assert_groups_close(out["obs_groups"], g, tag, 1e-6)
+    assert out["obs_groups"]["stack"].shape == (g.N, 2, 9) and out["obs_groups"]["terms"]["joint_vel"].shape == (g.N, 2, 12)
+
+
 def test_oracle_matches_reference_kitchen_sink():
     """The kitchen-sink fixture (oracle/gen_golden.py::kitchen_cfg, generated by the REAL managers, terms, RayCaster/SensorBase and
     the real ``modify_reward_weight``): every op of isaaclab.envs.mdp the four task configs do not use, two observation groups, the

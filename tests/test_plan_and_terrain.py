@@ -71,6 +71,28 @@ def test_term_compiler_matches_reference_term_tables(task):
     assert p.n_ext_rew == p.n_ext_term == p.n_ext_obs == 0  # everything in the target configs is fused
 
 
+def test_group_shapes_follow_the_reference():
+    """group_obs_term_dim / concatenate flags of a cfg with a dict-of-terms group and un-flattened history, against what the reference's
+    ObservationManager reported when the fixture was generated; terms of different rank cannot be concatenated (observation_manager.py:89-99)."""
+    import copy
+
+    from _util import SHAPES
+
+    g = Golden(SHAPES)
+    p = planmod.compile_plan(g.fixture["env"], g.robot)
+    assert [gr.name for gr in p.obs_groups] == g.meta["obs_groups"]
+    for gr in p.obs_groups:
+        assert [list(d) for d in gr.term_dims] == g.meta["obs_group_term_shapes"][gr.name]
+        assert gr.concatenate == g.meta["obs_group_concatenate"][gr.name] and gr.dim == sum(gr.term_widths)
+        assert [t.name for t in gr.terms] == g.meta["obs_group_terms"][gr.name]
+    assert [gr.dim for gr in p.obs_groups] == g.meta["obs_group_dims"]
+    assert [gr.is_flat for gr in p.obs_groups] == [True, False, False]
+    bad = copy.deepcopy(g.fixture["env"])
+    bad["observations"]["terms"]["concatenate_terms"] = True  # (2, 3) next to (12,)
+    with pytest.raises(RuntimeError, match="Unable to concatenate observation terms in group 'terms'"):
+        planmod.compile_plan(bad, g.robot)
+
+
 def test_term_compiler_errors_follow_the_reference():
     g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
     import copy
