@@ -399,6 +399,7 @@ PlanView imx_plan_view(const imx_plan* p) {
     v.gx = wf(w[IMX_H_GRAV_X]); v.gy = wf(w[IMX_H_GRAV_Y]); v.gz = wf(w[IMX_H_GRAV_Z]);
     v.rdx = wf(w[IMX_H_RAYDIR_X]); v.rdy = wf(w[IMX_H_RAYDIR_Y]); v.rdz = wf(w[IMX_H_RAYDIR_Z]);
     v.ray_max_dist = wf(w[IMX_H_RAY_MAXDIST]);
+    v.rinv_dz = 1.0f / v.rdz;
     v.ray_yaw_only = w[IMX_H_RAY_YAW_ONLY];
     return v;
 }

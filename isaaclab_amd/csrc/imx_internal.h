@@ -63,6 +63,7 @@ struct PlanView {
     float step_dt, max_ep_len_s;
     float gx, gy, gz;
     float rdx, rdy, rdz, ray_max_dist;
+    float rinv_dz;  // 1 / rdz, divided on the host (IEEE, the same bits as the in-kernel division it replaces: ~12 VALU per ray)
     int ray_yaw_only;
     int ngroups, gD[IMX_MAX_OBS_GROUPS], gbase[IMX_MAX_OBS_GROUPS], gcorrupt;
     int scan_stateful, scan_substeps;

@@ -200,10 +200,12 @@ IMX_DEV void take_hit(float t, int32_t f, float& best, int32_t& face) {
 // One cell, vertical ray.  `interior`: the ray is not within tau of a cell boundary (then a QH cell answers from its heights).
 IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
                            bool interior, float& best, int32_t& face) {
-    if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
+    if ((unsigned)ix >= (unsigned)m.nx || (unsigned)iy >= (unsigned)m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
-    const int4 a4 = m.cells[2 * (size_t)c];  // both halves of the cell and (lattice) its four grid lines: one load level
-    const int4 b4 = m.cells[2 * (size_t)c + 1];
+    // both halves of the cell: one load level.  32-bit byte offset from the (scalar) base -- the builder refuses grids beyond 2^27 cells
+    const int4* cp = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(m.cells) + ((uint32_t)c << 5));
+    const int4 a4 = cp[0];
+    const int4 b4 = cp[1];
     const int kind = b4.x;
     if (kind == IMX_CELL_LATTICE) {
         // Height-field quad a (x0,y0), d (x1,y0), c (x0,y1), b (x1,y1), split along a-b.  The ray is inside the quad or not by exact
@@ -244,12 +246,12 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
     }
 }
 
-IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, float dz, float max_dist, float& t_hit,
+// Sz = 1 / dz (the caller's: the observation kernel takes it from the plan, divided once on the host)
+IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, float dz, float Sz, float max_dist, float& t_hit,
                                int32_t& face) {
     float best = max_dist;
     face = -1;
     const bool flip = dz < 0.0f;
-    const float Sz = 1.0f / dz;
     int nbx, nby;
     const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
     const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);

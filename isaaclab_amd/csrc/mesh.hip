@@ -92,6 +92,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     const int ntx = (int)((nx + 7) / 8), nty = (int)((ny + 7) / 8);
     const int64_t ntile = (int64_t)ntx * nty;
     const int64_t ncell = ntile * 64;  // 8x8-tiled layout (imx_cell_index)
+    IMX_REQUIRE(ncell <= (1ll << 27), "imx_mesh_create: %lld grid cells (the ray path addresses cells by a 32-bit byte offset: at most 2^27); use a larger cell size", (long long)ncell);
 
     // ---- pass 1: per-triangle cell ranges, per-cell reference counts (CSR), ascending triangle ids per cell
     std::vector<int32_t> start((size_t)ncell + 1, 0);

@@ -844,7 +844,7 @@ IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __rest
                        float px, float py, float pz, float yw, float yz, float* __restrict__ ray_hits_out, int64_t e) {
     const float lx = ray_local[3 * j], ly = ray_local[3 * j + 1], lz = ray_local[3 * j + 2];
     float sx, sy, sz, dx = P.rdx, dy = P.rdy, dz = P.rdz;
-    if (P.ray_yaw_only) {
+    if (!GENERAL_RAYS || P.ray_yaw_only) {  // (the vertical-ray variant is only launched for a yaw-aligned sensor)
         quat_apply_yaw_only(yw, yz, lx, ly, lz, sx, sy, sz);
     } else {  // ray_caster.py:249-252: full orientation for starts and directions
         quat_apply(es[12], es[13], es[14], es[15], lx, ly, lz, sx, sy, sz);
@@ -854,7 +854,7 @@ IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __rest
     float t;
     int32_t face;
     const bool hit = GENERAL_RAYS ? cast_ray(M, sx, sy, sz, dx, dy, dz, P.ray_max_dist, t, face)
-                                  : cast_ray_vertical(M, sx, sy, sz, dz, P.ray_max_dist, t, face);
+                                  : cast_ray_vertical(M, sx, sy, sz, dz, P.rinv_dz, P.ray_max_dist, t, face);
     const float hz = hit ? sz + t * dz : __builtin_huge_valf();  // kernels.py:69
     if (ray_hits_out) {
         float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
@@ -877,7 +877,7 @@ template <bool GENERAL_RAYS>
 __global__ void __launch_bounds__(64)
 k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
            const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G,
-           int tail_parts, int scan_rec, int waves_per_env) {
+           int tail_parts, int scan_rec, int waves_per_env, uint32_t div_magic, int div_shift) {
     if ((int)blockIdx.x < tail_parts) {  // extra workgroups, first in the grid: the step tail k_term_rew deferred (kernel boundary = its partials are complete)
         step_tail(P, N, Bf, sc, tail_G, (int)blockIdx.x, tail_parts);
         return;
@@ -885,13 +885,15 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
     const unsigned b = blockIdx.x - (unsigned)tail_parts;
     int64_t e;
     int role;
+    // b / divisor by multiply-high with the host's magic number (two scalar instructions instead of the ~25 of a 32-bit division)
+    const uint32_t q = (uint32_t)(((uint64_t)b * div_magic) >> 32) >> div_shift;
     if (waves_per_env > 0) {
-        e = b / (unsigned)waves_per_env;
-        role = (int)(b - (unsigned)e * (unsigned)waves_per_env);
+        e = q;
+        role = (int)(b - q * (unsigned)waves_per_env);
     } else {  // role-major order (the host's choice for small grids)
         waves_per_env = -waves_per_env;
-        role = (int)(b / (unsigned)N);
-        e = b - (unsigned)role * (unsigned)N;
+        role = (int)q;
+        e = b - q * (unsigned)N;
     }
     const int32_t* __restrict__ W = P.w;
     const uint32_t step = (uint32_t)Bf.counters[2];
@@ -914,23 +916,26 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         const float yw = es[16], yz = es[17];
         const int j = role * 64 + (int)threadIdx.x;  // one ray per lane
         if (j >= P.R) return;
+        // per-env bases are wave-uniform (scalar); the lane adds a 32-bit column offset
+        float* __restrict__ obs_row = Bf.obs + e * D;
+        float* __restrict__ hitz_row = P.scan_stateful ? Bf.scan_hit_z + (size_t)e * P.R : nullptr;
         float hz;
         if (cast) {
             hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
-            if (cache_z) Bf.scan_hit_z[(size_t)e * P.R + j] = hz;
+            if (cache_z) hitz_row[(unsigned)j] = hz;
         } else {
-            hz = Bf.scan_hit_z[(size_t)e * P.R + j];  // data.ray_hits_w of the last update
+            hz = hitz_row[(unsigned)j];  // data.ray_hits_w of the last update
         }
         float v = pz - hz - off;
         const int c = out + j;
         if (noisy) {
-            const float u = noise_u ? noise_u[e * P.D + c] : uniform01(seed, step, (uint64_t)e * P.D + c);
+            const float u = noise_u ? (noise_u + e * P.D)[(unsigned)c] : uniform01(seed, step, (uint64_t)e * P.D + c);
             const float nz = u * (nhi - nlo) + nlo;  // noise_model.py:62-66
             v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
         }
         if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);
         if (flags & IMX_F_SCALE) v = v * scale;
-        Bf.obs[e * D + c] = v;
+        obs_row[(unsigned)c] = v;
     } else {
         if (e == 0 && threadIdx.x == 0) Bf.counters[3] = (int32_t)step;  // the shadow the next step kernel counts on from
         for (int i = P.n_ray_cols + (int)threadIdx.x; i < P.DC; i += 64) {  // xcol lists the ray columns first
@@ -1059,6 +1064,16 @@ __global__ void k_raycast(MeshView M, const float* __restrict__ starts, const fl
 }
 
 // ------------------------------------------------------------------------------------------------- C ABI
+// Magic number for floor(b / d), 0 <= b < 2^31, d >= 2: q = mulhi(b, magic) >> shift.  With l = ceil(log2 d) and magic =
+// floor(2^(31+l) / d) + 1 (< 2^32 because d > 2^(l-1)), b * magic / 2^(31+l) = b/d + eps with eps < 2^31 * d / (d * 2^(31+l)) <= 1/d:
+// never enough to carry frac(b/d) <= (d-1)/d over the next integer.
+static void imx_magic_u31(uint32_t d, uint32_t& magic, int& shift) {
+    int l = 1;
+    while ((1ull << l) < d) ++l;
+    magic = (uint32_t)(((1ull << (31 + l)) / d) + 1);
+    shift = l - 1;
+}
+
 static int check_common(const imx_plan_t* plan, int64_t N, const imx_state_t* st, const imx_buffers_t* bf) {
     IMX_REQUIRE(plan && st && bf, "null plan/state/buffers");
     IMX_REQUIRE(plan->dev, "plan has no device copy (no GPU visible when it was created)");
@@ -1230,14 +1245,18 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
         // Up to ~2 residency rounds the waves go out role by role (all envs' first 64 rays, ..., the short column waves last: a
         // shorter drain, 17.2 us against 18.6 at 4096 envs); beyond that env by env (an env's rays share mesh lines: 173 us against
         // 191 at 65536 envs).
-        const bool role_major = N <= 8192;
+        const bool role_major = N <= 8192 && N >= 2;
+        const uint32_t divisor = role_major ? (uint32_t)N : (uint32_t)wpe;
+        uint32_t div_magic = 0;
+        int div_shift = 0;
+        imx_magic_u31(divisor, div_magic, div_shift);
         const unsigned lgrid = (unsigned)(N * wpe) + (unsigned)tail_parts;
         if (vertical)
             hipLaunchKernelGGL(k_obs_lean<false>, dim3(lgrid), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed,
-                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe);
+                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe, div_magic, div_shift);
         else
             hipLaunchKernelGGL(k_obs_lean<true>, dim3(lgrid), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed,
-                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe);
+                               enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts, scan_rec, role_major ? -wpe : wpe, div_magic, div_shift);
     } else {
         if (tail) tail_parts = 1 + ((nlog < 16 ? nlog : 16) * 64 + bs - 1) / bs;
         const unsigned grid = (unsigned)N + (unsigned)tail_parts;
