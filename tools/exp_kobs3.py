@@ -6,7 +6,8 @@ from bench import build_env
 from tools.exp_obs_util import timeit
 
 dev = torch.device("cuda:0")
-fx, env, ntri = build_env("Isaac-Velocity-Rough-Anymal-C-v0", 4096, dev, 42, 4, (10, 20))
+NENV = int(os.environ.get("IMX_EXP_N", "4096"))
+fx, env, ntri = build_env("Isaac-Velocity-Rough-Anymal-C-v0", NENV, dev, 42, 4, (10, 20))
 env.reset()
 def f():
     env._compute_observations(frame_current=True)
@@ -43,6 +44,6 @@ for name, kinds in (("lattice-only envs", (3, 7, 8, 9)), ("general-only envs", (
     moved()
     print("%-27s %.1f us" % (name, timeit(f)))
 pos.copy_(saved)
-fx2, env2, _ = build_env("Isaac-Velocity-Flat-Anymal-C-v0", 4096, dev, 42, 4, (10, 20))
+fx2, env2, _ = build_env("Isaac-Velocity-Flat-Anymal-C-v0", NENV, dev, 42, 4, (10, 20))
 env2.reset()
 print("flat task (D=48, no rays)   %.1f us" % timeit(lambda: env2._compute_observations(frame_current=True)))
