@@ -200,6 +200,55 @@ def test_full_size_against_cpu_oracle(task, N):
     env2.close()
 
 
+def test_height_scanner_rays_along_cell_boundaries():
+    """Every ray of every env within a few 1e-5 m of a grid line of the terrain's cell grid (sensor on a grid node +- 2e-5 .. 5e-5 m,
+    yaw a multiple of 90 degrees, ray pattern pitch = cell size): the paths for rays within tau of a cell boundary -- neighbour cells,
+    reference lists, or the builder's proof that the cell's own record is complete there -- against the fp64 brute force over ALL
+    triangles, on box, stair and height-field tiles."""
+    from isaaclab_amd.env import ManagerBasedRLEnv, load_task_cfg
+    from isaaclab_amd.robots import ROBOTS
+    from isaaclab_amd.state_feed import StateFeed
+    from isaaclab_amd.terrain import make_rough_terrain
+    from oracle.mdp_oracle import quat_apply_yaw
+    from oracle.raycast import raycast_f64
+
+    task, N = "Isaac-Velocity-Rough-Anymal-C-v0", 512
+    fx = load_task_cfg(task)
+    robot = ROBOTS[fx["robot"]]
+    v, t, e = make_rough_terrain(4, 6, tile=8.0, border=5.0, seed=3)
+    feed = StateFeed(robot, N, "cpu", seed=11, num_snapshots=2, extent_xy=(e[0] - 1.0, e[1] - 1.0))
+    gen = torch.Generator().manual_seed(3)
+    pos, quat = feed._stack["root_pos_w"], feed._stack["root_quat_w"]
+    node = torch.stack([torch.randint(-140, 141, (N,), generator=gen), torch.randint(-220, 221, (N,), generator=gen)], 1).float() * 0.1
+    jitter = torch.tensor([-5e-5, -2e-5, 2e-5, 5e-5])[torch.randint(0, 4, (N, 2), generator=gen)]
+    jitter[::7] = torch.tensor([3e-4, -3e-4])  # and some clear of the tau band, for contrast
+    pos[:, :, :2] = (node + jitter).unsqueeze(0)
+    yaw = torch.randint(0, 4, (N,), generator=gen).float() * (torch.pi / 2)
+    quat[:] = torch.stack([torch.cos(yaw / 2), torch.zeros(N), torch.zeros(N), torch.sin(yaw / 2)], 1).unsqueeze(0)
+    gpu_feed = StateFeed.from_tensors(robot, [feed.snapshot(i) for i in range(2)], "cuda:0", feed.gravity_dir)
+    env = ManagerBasedRLEnv(fx, state_feed=gpu_feed, terrain=(v, t), terrain_cell=0.1)
+    env.materialize_ray_hits = True
+    env.plan.enable_corruption = False
+    obs_dict, _ = env.reset()
+    R = env.plan.num_rays
+    local = torch.from_numpy(env.plan.ray_starts_local).unsqueeze(0).repeat(N, 1, 1)
+    starts = quat_apply_yaw(feed["root_quat_w"].repeat(1, R), local) + feed["root_pos_w"].unsqueeze(1)
+    # the premise: (almost) every ray sits within tau = 1e-3 cells of a grid line
+    g = (starts[..., :2].reshape(-1, 2).double() - torch.tensor([float(v[:, 0].min()), float(v[:, 1].min())]).double()) / 0.1
+    near = ((g - g.round()).abs() < 1e-3).any(1).float().mean()
+    assert near > 0.8, float(near)
+    dirs = torch.tensor(env.plan.ray_direction).repeat(N * R, 1)
+    h64, _, _ = raycast_f64(v, t, starts.reshape(-1, 3).numpy(), dirs.numpy())
+    got = env._ray_hits.cpu().reshape(-1, 3)
+    assert torch.isfinite(got).all(1).float().mean() > 0.99
+    assert_close(got, torch.from_numpy(h64), FLOAT_TOL, "boundary rays vs fp64 brute force")
+    # and through to the observation columns: height_scan = sensor z - hit z - offset, clipped
+    scan = obs_dict["policy"][:, -R:].cpu()
+    want = (feed["root_pos_w"][:, 2:3] - torch.from_numpy(h64).view(N, R, 3)[..., 2] - 0.5).clip(-1.0, 1.0)
+    assert_close(scan, want.float(), FLOAT_TOL, "height_scan columns")
+    env.close()
+
+
 def test_in_kernel_noise_is_uniform_and_bounded():
     g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
     env = make_env(g)
