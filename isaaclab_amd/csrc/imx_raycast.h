@@ -105,7 +105,7 @@ IMX_DEV void test_cell(const MeshView& m, const WoopRay& r, int ix, int iy, floa
     if (ix < 0 || iy < 0 || ix >= m.nx || iy >= m.ny) return;
     const int c = imx_cell_index(ix, iy, m.ntx);
     const int4 b4 = m.cells[2 * (size_t)c + 1];
-    const int kind = b4.x;
+    const int kind = b4.x & 0xFF;
     if (kind == IMX_CELL_LATTICE) {  // the quad's corners: grid lines x heights
         const int4 a4 = m.cells[2 * (size_t)c];
         const float x0 = m.gx[ix], x1 = m.gx[ix + 1], y0 = m.gy[iy], y1 = m.gy[iy + 1];
@@ -197,16 +197,23 @@ IMX_DEV void take_hit(float t, int32_t f, float& best, int32_t& face) {
     }
 }
 
+// bit of the neighbour (dx, dy) in a cell's continuity mask (bits 8.. of the kind word, mesh.hip pass 2b)
+IMX_DEV int imx_nb_bit(int dx, int dy) { return 8 + (dy + 1) * 3 + (dx + 1); }
+
 // One cell, vertical ray.  `interior`: the ray is not within tau of a cell boundary (then a QH cell answers from its heights).
-IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
-                           bool interior, float& best, int32_t& face) {
-    if ((unsigned)ix >= (unsigned)m.nx || (unsigned)iy >= (unsigned)m.ny) return;
+// `need`: for a ray within tau of a boundary of ITS cell, the continuity bits of the neighbours it would have to visit; when the cell has
+// them all, the surface is proven continuous across those boundaries (mesh.hip pass 2b) and the cell's own record answers the ray like an
+// interior one.  Returns true when it did -- the caller then skips the neighbours.
+IMX_DEV bool vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
+                           bool interior, int need, float& best, int32_t& face) {
+    if ((unsigned)ix >= (unsigned)m.nx || (unsigned)iy >= (unsigned)m.ny) return false;
     const int c = imx_cell_index(ix, iy, m.ntx);
     // both halves of the cell: one load level.  32-bit byte offset from the (scalar) base -- the builder refuses grids beyond 2^27 cells
     const int4* cp = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(m.cells) + ((uint32_t)c << 5));
     const int4 a4 = cp[0];
     const int4 b4 = cp[1];
-    const int kind = b4.x;
+    const int kind = b4.x & 0xFF;
+    const bool complete = need != 0 && (b4.x & need) == need;
     if (kind == IMX_CELL_LATTICE) {
         // Height-field quad a (x0,y0), d (x1,y0), c (x0,y1), b (x1,y1), split along a-b.  The ray is inside the quad or not by exact
         // comparisons with its coordinate lines (neighbouring quads share them: no gaps, a ray ON a line is in both and gets the
@@ -219,9 +226,10 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
             const bool upper = w >= u;  // the (a, b, c) side of the diagonal
             const float z = upper ? za + ((zb - zc) * u + (zc - za) * w) : za + ((zd - za) * u + (zb - zd) * w);
             take_hit(Sz * (z - oz), b4.y + (upper ? 0 : 1), best, face);
+            return complete;  // inside this quad, and the quads across the near boundaries continue it with the same corner heights
         }
     } else if (kind == IMX_CELL_QH) {
-        if (interior && flip) {
+        if ((interior || complete) && flip) {
             // the highest surface is horizontal on either side of the lines x = cx, y = cy; a ray exactly on a line touches both sides
             // and the closest hit is the higher one
             const float cx = __int_as_float(b4.y), cy = __int_as_float(b4.z);
@@ -231,6 +239,7 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
             const float on = oy == cy ? fmaxf(ox <= cx ? fmaxf(h00, h01) : -__builtin_huge_valf(), ox >= cx ? fmaxf(h10, h11) : -__builtin_huge_valf())
                                       : -__builtin_huge_valf();
             take_hit(Sz * (fmaxf(fmaxf(lo, hi), on) - oz), b4.w, best, face);
+            return complete;
         } else {  // a ray on a cell boundary, or an upward one: the full list
             const int2 g = m.cell_list[c];
             vertical_list(m, g.x, g.x + g.y, ox, oy, oz, flip, Sz, dz, best, face);
@@ -241,9 +250,10 @@ IMX_DEV void vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
         vertical_record(m, a4.z, ox, oy, oz, flip, Sz, best, face);
         // references are sorted by descending top; a4.w = highest top among those after this pair.  A downward
         // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
-        if (flip && face >= 0 && __int_as_float(a4.w) < oz + best * dz) return;
+        if (flip && face >= 0 && __int_as_float(a4.w) < oz + best * dz) return false;
         vertical_list(m, b4.y + 2, b4.y + b4.z, ox, oy, oz, flip, Sz, dz, best, face);
     }
+    return false;
 }
 
 // Sz = 1 / dz (the caller's: the observation kernel takes it from the plan, divided once on the host)
@@ -255,11 +265,15 @@ IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, 
     int nbx, nby;
     const int ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
     const int iy = cell_of((oy - m.y0) * m.inv_cell, nby);
-    vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, (nbx | nby) == 0, best, face);
-    if (nbx | nby) {  // within tau of a cell boundary (rare): the neighbouring cells as well
-        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, false, best, face);
-        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, false, best, face);
-        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, false, best, face);
+    int need = 0;
+    if (nbx) need |= 1 << imx_nb_bit(nbx, 0);
+    if (nby) need |= 1 << imx_nb_bit(0, nby);
+    if (nbx && nby) need |= 1 << imx_nb_bit(nbx, nby);
+    const bool settled = vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, (nbx | nby) == 0, need, best, face);
+    if ((nbx | nby) && !settled) {  // within tau of a cell boundary the surface is not known to continue across: the neighbouring cells as well
+        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
+        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
+        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
     }
     if (face < 0) return false;
     t_hit = best;

@@ -349,6 +349,117 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                 cb[2] = npad;
             }
         }
+    // ---- pass 2b: continuity masks.  A vertical ray within tau of a boundary of its cell must normally look into the neighbouring
+    // cell(s) as well (a triangle reaching < tau into a cell is only listed on the other side) and, on QH cells, walk the reference
+    // lists: three or four dependent loads for 0.4 % of the rays -- but a quarter of all 64-ray waves has one.  Most of those boundaries
+    // run through the middle of a box top, a stair tread, flat ground or a height field.  Bit 8 + 3 (dy + 1) + (dx + 1) of the kind word
+    // says: across the boundary towards neighbour (dx, dy) the highest surface CONTINUES -- then the cell's own record answers the ray:
+    //   LATTICE | LATTICE   the quads share their corner heights along the common edge (corner for a diagonal neighbour);
+    //   QH | QH             the heights on either side of the common edge agree part by part (same split line across, or no step along
+    //                       the edge at all) and no horizontal face listed in either cell lies higher anywhere in the 2 tau band
+    //                       around the edge (the band is outside both cells' own proofs; QH lists hold horizontal faces and walls only);
+    //   x | EMPTY           nothing is listed over there (same band check on the cell's own list).
+    // Everything else (QH next to LATTICE, GENERAL anywhere, unequal heights = a real edge) keeps the bit clear: full path, as before.
+    int64_t n_cont_bits = 0, n_cont_cells = 0;
+    {
+        const double band = 2.0 * (double)IMX_GRID_TAU;
+        auto kind_at = [&](int ix, int iy) -> int {
+            if (ix < 0 || iy < 0 || ix >= (int)nx || iy >= (int)ny) return IMX_CELL_EMPTY;
+            return cellv[(size_t)imx_cell_index(ix, iy, ntx) * 8 + 4] & 0xFF;
+        };
+        auto fl = [&](int32_t w) { float f; memcpy(&f, &w, 4); return f; };
+        // a horizontal face of cell c's list above height h with xy-extent reaching into [x0,x1] x [y0,y1] (grid units)?
+        auto higher_face = [&](int c, double x0, double y0, double x1, double y1, float h) -> bool {
+            for (int k = start[c]; k < start[c + 1]; ++k) {
+                const float* rec = &recs[(size_t)refs[k] * 12];
+                if (!(rec[2] == rec[5] && rec[5] == rec[8]) || !(rec[2] > h)) continue;
+                const double gx0 = std::min({grid_x(rec[0]), grid_x(rec[3]), grid_x(rec[6])}), gx1 = std::max({grid_x(rec[0]), grid_x(rec[3]), grid_x(rec[6])});
+                const double gy0 = std::min({grid_y(rec[1]), grid_y(rec[4]), grid_y(rec[7])}), gy1 = std::max({grid_y(rec[1]), grid_y(rec[4]), grid_y(rec[7])});
+                if (gx1 > x0 && gx0 < x1 && gy1 > y0 && gy0 < y1) return true;
+            }
+            return false;
+        };
+        for (int iy = 0; iy < (int)ny; ++iy)
+            for (int ix = 0; ix < (int)nx; ++ix) {
+                const int c = imx_cell_index(ix, iy, ntx);
+                int32_t* ca = &cellv[(size_t)c * 8];
+                int32_t* cb = ca + 4;
+                const int kc = cb[0] & 0xFF;
+                if (kc != IMX_CELL_LATTICE && kc != IMX_CELL_QH) continue;
+                uint32_t mask = 0;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int kn = kind_at(ix + dx, iy + dy);
+                        const bool in_grid = ix + dx >= 0 && iy + dy >= 0 && ix + dx < (int)nx && iy + dy < (int)ny;
+                        const int cn = in_grid ? imx_cell_index(ix + dx, iy + dy, ntx) : -1;
+                        const int32_t* na = in_grid ? &cellv[(size_t)cn * 8] : nullptr;
+                        bool ok = false;
+                        // the band around the common edge / corner, in grid units
+                        const double bx0 = dx < 0 ? ix - band : (dx > 0 ? ix + 1 - band : ix - band), bx1 = dx < 0 ? ix + band : (dx > 0 ? ix + 1 + band : ix + 1 + band);
+                        const double by0 = dy < 0 ? iy - band : (dy > 0 ? iy + 1 - band : iy - band), by1 = dy < 0 ? iy + band : (dy > 0 ? iy + 1 + band : iy + 1 + band);
+                        if (kc == IMX_CELL_LATTICE) {
+                            // corners: [0] a (ix,iy)  [1] d (ix+1,iy)  [2] c (ix,iy+1)  [3] b (ix+1,iy+1)
+                            auto corner = [&](const int32_t* q, int cx_, int cy_) { return q[cy_ * 2 + cx_]; };
+                            if (kn == IMX_CELL_EMPTY) ok = true;
+                            else if (kn == IMX_CELL_LATTICE) {
+                                ok = true;
+                                // every corner of this quad that lies on the common edge / corner is the same height in the neighbour's quad
+                                for (int qy = 0; qy < 2 && ok; ++qy)
+                                    for (int qx = 0; qx < 2 && ok; ++qx) {
+                                        const int nxq = qx - dx, nyq = qy - dy;  // the same vertex in the neighbour's corner numbering
+                                        if (nxq < 0 || nxq > 1 || nyq < 0 || nyq > 1) continue;
+                                        ok = corner(ca, qx, qy) == corner(na, nxq, nyq);
+                                    }
+                            }
+                        } else {  // QH: [0] h00 (x<cx,y<cy) [1] h10 [2] h01 [3] h11; cb[1] = cx, cb[2] = cy (+inf: no split)
+                            auto hq = [&](const int32_t* q, int qx, int qy) { return q[qy * 2 + qx]; };
+                            const int sx = dx > 0 ? 1 : 0, sy = dy > 0 ? 1 : 0;  // this cell's half towards the neighbour (per axis)
+                            if (kn == IMX_CELL_EMPTY || kn == IMX_CELL_QH) {
+                                const int32_t* nb_ = kn == IMX_CELL_QH ? na + 4 : nullptr;
+                                ok = true;
+                                float hmax = -INFINITY;  // the heights this cell claims along the edge
+                                if (dx != 0 && dy != 0) {
+                                    hmax = fl(hq(ca, sx, sy));
+                                    if (kn == IMX_CELL_QH) ok = hq(ca, sx, sy) == hq(na, 1 - sx, 1 - sy);
+                                } else if (dx != 0) {
+                                    hmax = std::max(fl(hq(ca, sx, 0)), fl(hq(ca, sx, 1)));
+                                    if (kn == IMX_CELL_QH)
+                                        ok = hq(ca, sx, 0) == hq(na, 1 - sx, 0) && hq(ca, sx, 1) == hq(na, 1 - sx, 1) &&
+                                             (cb[2] == nb_[2] || (hq(ca, sx, 0) == hq(ca, sx, 1) && hq(na, 1 - sx, 0) == hq(na, 1 - sx, 1)));
+                                } else {
+                                    hmax = std::max(fl(hq(ca, 0, sy)), fl(hq(ca, 1, sy)));
+                                    if (kn == IMX_CELL_QH)
+                                        ok = hq(ca, 0, sy) == hq(na, 0, 1 - sy) && hq(ca, 1, sy) == hq(na, 1, 1 - sy) &&
+                                             (cb[1] == nb_[1] || (hq(ca, 0, sy) == hq(ca, 1, sy) && hq(na, 0, 1 - sy) == hq(na, 1, 1 - sy)));
+                                }
+                                // nothing higher hides in the band.  With a step ALONG the edge the lower part could still have a face between
+                                // the two heights: compare against the lower of the claimed heights there (conservative)
+                                float hmin = hmax;
+                                if (dx != 0 && dy == 0) hmin = std::min(fl(hq(ca, sx, 0)), fl(hq(ca, sx, 1)));
+                                if (dy != 0 && dx == 0) hmin = std::min(fl(hq(ca, 0, sy)), fl(hq(ca, 1, sy)));
+                                if (ok && hmin != hmax) {
+                                    // the higher part's own faces are above hmin by design: check part by part along the edge
+                                    const float cut = dx != 0 ? fl(cb[2]) : fl(cb[1]);  // the split coordinate along the edge (world)
+                                    const double gcut = dx != 0 ? grid_y(cut) : grid_x(cut);
+                                    for (int part = 0; part < 2 && ok; ++part) {
+                                        const float hp = dx != 0 ? fl(hq(ca, sx, part)) : fl(hq(ca, part, sy));
+                                        double px0 = bx0, px1 = bx1, py0 = by0, py1 = by1;
+                                        if (dx != 0) { if (part == 0) py1 = gcut; else py0 = gcut; } else { if (part == 0) px1 = gcut; else px0 = gcut; }
+                                        ok = !higher_face(c, px0, py0, px1, py1, hp) && (cn < 0 || !higher_face(cn, px0, py0, px1, py1, hp));
+                                    }
+                                } else if (ok) {
+                                    ok = !higher_face(c, bx0, by0, bx1, by1, hmax) && (cn < 0 || !higher_face(cn, bx0, by0, bx1, by1, hmax));
+                                }
+                            }
+                        }
+                        if (ok) mask |= 1u << (3 * (dy + 1) + (dx + 1));
+                    }
+                cb[0] |= (int32_t)(mask << 8);
+                n_cont_bits += __builtin_popcount(mask);
+                n_cont_cells += (mask & 0x1EFu) == 0x1EFu;
+            }
+    }
     for (auto& v : gxl) if (std::isnan(v)) v = 0.0f;  // lines no lattice cell uses
     for (auto& v : gyl) if (std::isnan(v)) v = 0.0f;
     if (getenv("IMX_MESH_STATS")) {  // debugging aid: histogram of references per general cell
@@ -356,7 +467,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         int64_t degenerate = 0, total = 0;
         for (int64_t c = 0; c < ncell; ++c) {
             const int n = start[c + 1] - start[c];
-            if (n == 0 || cellv[(size_t)c * 8 + 4] == IMX_CELL_LATTICE) continue;
+            if (n == 0 || (cellv[(size_t)c * 8 + 4] & 0xFF) == IMX_CELL_LATTICE) continue;
             int nv = 0;
             for (int k = 0; k < n; ++k) {
                 const uint32_t* t = tris + 3 * (size_t)refs[start[c] + k];
@@ -371,6 +482,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)hist[i]);
         fprintf(stderr, "\n[imx mesh] general cells by #non-degenerate refs:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)histv[i]);
+        fprintf(stderr, "\n[imx mesh] continuity: %lld cells with all 8 neighbours continuous, %lld bits set (of %lld)", (long long)n_cont_cells, (long long)n_cont_bits, (long long)(8 * (n_lattice + n_flat)));
         fprintf(stderr, "\n[imx mesh] degenerate (zero xy-area) refs %lld of %lld\n", (long long)degenerate, (long long)total);
     }
     IMX_REQUIRE(refl.size() / 2 < (1ull << 31), "imx_mesh_create: too many general cell references");
