@@ -74,13 +74,14 @@ PlanView imx_plan_view(const imx_plan* p);
 // ---- mesh ---------------------------------------------------------------------------------------------------------
 // Cells of the xy grid are stored in 8x8 tiles (tile-major), so the ~17x11-cell footprint of one height scanner maps to a handful
 // of contiguous runs.  32 bytes per cell: a = four floats, b = {kind, ...} (mesh.hip pass 2 says what qualifies):
-//   kind 0 EMPTY
+//   kind (low 8 bits of b.x; bits 8..16 = continuity mask of LATTICE / QH cells, mesh.hip pass 2b) 0 EMPTY
 //        1 LATTICE  the two triangles (a,b,c),(a,d,b) of one height-field quad (convert_height_field_to_mesh topology) with corners
 //                   on the grid's coordinate lines gx[ix], gx[ix+1], gy[iy], gy[iy+1]: a = heights of a (ix,iy), d (ix+1,iy),
 //                   c (ix,iy+1), b (ix+1,iy+1); b.y = face id of (a,b,c), the other triangle is b.y + 1
 //        2 QH       the highest surface over the cell's interior is horizontal in each of the <= 4 rectangles the lines x = cx,
 //                   y = cy cut it into: a = {h00 (x<cx,y<cy), h10, h01, h11}; b = {kind, cx, cy, a face id} (+inf = no line)
-//        3 GENERAL  a = {-, id0, id1, zrest after the first pair}; b = {kind, first reference, count (even)}
+//        3 GENERAL  a = {id2, id0, id1, zrest after the first pair}; b = {kind, first reference, count (even), id3}: the first two
+//                   pairs of its reference list inline
 //   QH and GENERAL cells also have cell_list[c] = {first reference, count}: a reference is {triangle id, zrest}, sorted by descending
 //   triangle top (max z), zrest = highest top among the references after it (a downward ray stops once its hit is above zrest);
 //   refs holds them as pairs {id0, zrest0, id1, zrest1}.  Triangle records (48 B, ONE per triangle, shared by all the cells that

@@ -163,7 +163,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
     //   QH       ("quad heights") the highest surface over the cell's interior is horizontal in each of the <= 4 rectangles an
     //            axis-aligned line x = cx and / or y = cy cuts the cell into -- box tops, stair treads, platforms, their edges and
     //            corners, the plateaus of a snapped height field: a = the four heights, b = {kind, cx, cy, a face id};
-    //   GENERAL  everything else: a = {-, id0, id1, zrest} (first reference pair inline), b = {kind, first reference, count}.
+    //   GENERAL  everything else: a = {id2, id0, id1, zrest} b = {kind, first reference, count, id3} (the first two reference pairs inline).
     // QH and GENERAL cells also keep their full reference list (cell_list -> refs -> 48-byte triangle records, one record per
     // TRIANGLE shared by all cells): slanted rays, upward rays and rays within tau of a cell boundary walk it.
     std::vector<int32_t> cellv((size_t)ncell * 8, 0);
@@ -189,6 +189,8 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         if ((rec[0] == rec[3] && rec[3] == rec[6]) || (rec[1] == rec[4] && rec[4] == rec[7])) ztop[f] = -INFINITY;
     }
     int64_t n_lattice = 0, n_general = 0, n_flat = 0;
+    int64_t why_general[4] = {0, 0, 0, 0};  // statistics (IMX_MESH_STATS): a sloped triangle / two split lines on one axis / a rectangle not covered / other
+    std::vector<int64_t> gen_refs(17, 0);
     auto single_cell = [&](int32_t f) {
         return ra[(size_t)f * 4] == ra[(size_t)f * 4 + 1] && ra[(size_t)f * 4 + 2] == ra[(size_t)f * 4 + 3];
     };
@@ -277,7 +279,7 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                 const float* rec = &recs[(size_t)r[k] * 12];
                 const bool horizontal = rec[2] == rec[5] && rec[5] == rec[8];
                 const bool wall = ztop[(size_t)r[k]] == -INFINITY;
-                if (!horizontal && !wall) { qh = false; break; }  // a sloped triangle: the Woop path
+                if (!horizontal && !wall) { qh = false; ++why_general[0]; break; }  // a sloped triangle: the Woop path
                 double g[3][2];
                 for (int cc = 0; cc < 3; ++cc) { g[cc][0] = grid_x(rec[cc * 3]); g[cc][1] = grid_y(rec[cc * 3 + 1]); }
                 if (horizontal) hf.push_back({g[0][0], g[0][1], g[1][0], g[1][1], g[2][0], g[2][1], (double)rec[2]});
@@ -285,10 +287,10 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                     const int e2 = (e + 1) % 3;
                     const float xa = rec[e * 3], ya = rec[e * 3 + 1], xb = rec[e2 * 3], yb = rec[e2 * 3 + 1];
                     if (xa == xb && g[e][0] > sx0 && g[e][0] < sx1 && std::max(g[e][1], g[e2][1]) > sy0 && std::min(g[e][1], g[e2][1]) < sy1) {
-                        if (cxw == INFINITY) { cxw = xa; cxg = g[e][0]; } else if (cxw != xa) qh = false;
+                        if (cxw == INFINITY) { cxw = xa; cxg = g[e][0]; } else if (cxw != xa) { if (qh) ++why_general[1]; qh = false; }
                     }
                     if (ya == yb && g[e][1] > sy0 && g[e][1] < sy1 && std::max(g[e][0], g[e2][0]) > sx0 && std::min(g[e][0], g[e2][0]) < sx1) {
-                        if (cyw == INFINITY) { cyw = ya; cyg = g[e][1]; } else if (cyw != ya) qh = false;
+                        if (cyw == INFINITY) { cyw = ya; cyg = g[e][1]; } else if (cyw != ya) { if (qh) ++why_general[1]; qh = false; }
                     }
                 }
             }
@@ -338,9 +340,12 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
                 cb[3] = face_q;
                 ++n_flat;
             } else {
-                // the first pair of references rides in the cell itself: {-, id0, id1, zrest after the pair}
+                ++gen_refs[std::min(n, 16)];
+                // the first two pairs of references ride in the cell itself: {id2, id0, id1, zrest after the first pair} {kind, first, count, id3}
                 ca[1] = key[0];
                 ca[2] = key[1];
+                ca[0] = key[npad > 2 ? 2 : 1];
+                cb[3] = key[npad > 2 ? 3 : 1];
                 float zr = -INFINITY;
                 for (int k = 2; k < n; ++k) zr = std::max(zr, order[k].first);
                 memcpy(&ca[3], &zr, 4);
@@ -482,6 +487,8 @@ extern "C" int imx_mesh_create(const float* verts, int64_t V, const uint32_t* tr
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)hist[i]);
         fprintf(stderr, "\n[imx mesh] general cells by #non-degenerate refs:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)histv[i]);
+        fprintf(stderr, "\n[imx mesh] GENERAL cells %lld: sloped triangle %lld, two split lines on an axis %lld; by #refs:", (long long)(n_general - n_flat), (long long)why_general[0], (long long)why_general[1]);
+        for (int i = 0; i <= 16; ++i) fprintf(stderr, " %d:%lld", i, (long long)gen_refs[i]);
         fprintf(stderr, "\n[imx mesh] continuity: %lld cells with all 8 neighbours continuous, %lld bits set (of %lld)", (long long)n_cont_cells, (long long)n_cont_bits, (long long)(8 * (n_lattice + n_flat)));
         fprintf(stderr, "\n[imx mesh] degenerate (zero xy-area) refs %lld of %lld\n", (long long)degenerate, (long long)total);
     }

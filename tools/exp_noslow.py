@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from isaaclab_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "libimx_noslow.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "libimx_%s.so" % os.environ.get("IMX_EXP_LIB", "noslow"))
 import runpy
 sys.argv = ["step_bench.py"] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, "tools", "step_bench.py"), run_name="__main__")
