@@ -207,8 +207,13 @@ IMX_DEV int imx_nb_bit(int dx, int dy) { return 8 + (dy + 1) * 3 + (dx + 1); }
 // `need`: for a ray within tau of a boundary of ITS cell, the continuity bits of the neighbours it would have to visit; when the cell has
 // them all, the surface is proven continuous across those boundaries (mesh.hip pass 2b) and the cell's own record answers the ray like an
 // interior one.  Returns true when it did -- the caller then skips the neighbours.
+// `defer`: when given, a GENERAL cell hit by a downward ray is not evaluated here; its inline references go to *defer for the wave to
+// work them off together (cast_ray_vertical_wave).
+struct GeneralCell {
+    int id0, id1, id2, id3, first, count;  // count == 0: nothing deferred
+};
 IMX_DEV bool vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy, float oz, bool flip, float Sz, float dz,
-                           bool interior, int need, float& best, int32_t& face) {
+                           bool interior, int need, float& best, int32_t& face, GeneralCell* defer = nullptr) {
     if ((unsigned)ix >= (unsigned)m.nx || (unsigned)iy >= (unsigned)m.ny) return false;
     const int c = imx_cell_index(ix, iy, m.ntx);
     // both halves of the cell: one load level.  32-bit byte offset from the (scalar) base -- the builder refuses grids beyond 2^27 cells
@@ -252,6 +257,10 @@ IMX_DEV bool vertical_cell(const MeshView& m, int ix, int iy, float ox, float oy
         return false;
 #endif
         // the first two pairs of references ride in the cell itself: {id2, id0, id1, zrest after the first pair} {kind, first, count, id3}
+        if (defer && flip) {
+            defer->id0 = a4.y; defer->id1 = a4.z; defer->id2 = a4.x; defer->id3 = b4.w; defer->first = b4.y; defer->count = b4.z;
+            return false;
+        }
         vertical_pair(m, a4.y, a4.z, ox, oy, oz, flip, Sz, best, face);
         // references are sorted by descending top; a4.w = highest top among those after this pair.  A downward
         // ray whose hit already lies above all of them is done (box bottoms, lower steps, ... are never loaded).
@@ -280,6 +289,82 @@ IMX_DEV bool cast_ray_vertical(const MeshView& m, float ox, float oy, float oz, 
 #endif
     const bool settled = vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, (nbx | nby) == 0, need, best, face);
     if ((nbx | nby) && !settled) {  // within tau of a cell boundary the surface is not known to continue across: the neighbouring cells as well
+        if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
+        if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
+        if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
+    }
+    if (face < 0) return false;
+    t_hit = best;
+    return true;
+}
+
+// cast_ray_vertical for a whole wave at once -- ALL 64 lanes must call it together (`active`: this lane has a ray).  Same results.
+// The difference is the GENERAL cells: one such lane (0.5 % of the bench terrain's cells, but three of an env's 187 rays on a snapped
+// height field) used to keep its wave for two to four extra round trips while 60 lanes idled.  Here the lanes that met a GENERAL cell
+// hand their up to four inline triangle references to the wave: lane 4 s + k tests reference k of the s-th such ray (16 rays per
+// round), ONE round trip and ONE triangle test for everybody, a quad minimum, and the owner collects its hit.  Longer lists (> 4
+// references, 18 % of the GENERAL cells) continue on their own lane as before.
+IMX_DEV bool cast_ray_vertical_wave(const MeshView& m, bool active, float ox, float oy, float oz, float dz, float Sz, float max_dist,
+                                    float& t_hit) {
+    float best = max_dist;
+    int32_t face = -1;
+    const bool flip = dz < 0.0f;
+    int nbx = 0, nby = 0, ix = 0, iy = 0;
+    bool settled = true;
+    GeneralCell gc;
+    gc.id0 = gc.id1 = gc.id2 = gc.id3 = gc.first = gc.count = 0;
+    if (active) {
+        ix = cell_of((ox - m.x0) * m.inv_cell, nbx);
+        iy = cell_of((oy - m.y0) * m.inv_cell, nby);
+        int need = 0;
+        if (nbx) need |= 1 << imx_nb_bit(nbx, 0);
+        if (nby) need |= 1 << imx_nb_bit(0, nby);
+        if (nbx && nby) need |= 1 << imx_nb_bit(nbx, nby);
+        settled = vertical_cell(m, ix, iy, ox, oy, oz, flip, Sz, dz, (nbx | nby) == 0, need, best, face, &gc);
+    }
+    const uint64_t mask = __ballot(gc.count > 0);
+    if (mask != 0ull) {  // wave-uniform
+        const int lane = (int)__lane_id();
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));  // owners below this lane
+        const bool owner = gc.count > 0;
+        const int total = __popcll(mask);
+        const float inf = __builtin_huge_valf();
+        float mine = inf;
+        for (int base = 0; base < total; base += 16) {
+            // the owners of this round post their lane number to lane (rank - base); everybody else posts to lanes >= 16 (ignored)
+            const bool in_round = owner && rank >= base && rank < base + 16;
+            const int dst = in_round ? rank - base : 16 + (lane % 48);
+            const int posted = __builtin_amdgcn_ds_permute(dst << 2, lane);
+            const int slot = lane >> 2, k = lane & 3;
+            const bool valid = slot < min(16, total - base);
+            const int own = valid ? __builtin_amdgcn_ds_bpermute(slot << 2, posted) : lane;
+            const int a0 = __builtin_amdgcn_ds_bpermute(own << 2, gc.id0), a1 = __builtin_amdgcn_ds_bpermute(own << 2, gc.id1);
+            const int a2 = __builtin_amdgcn_ds_bpermute(own << 2, gc.id2), a3 = __builtin_amdgcn_ds_bpermute(own << 2, gc.id3);
+            const float rx = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(ox)));
+            const float ry = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(oy)));
+            const float rz = __int_as_float(__builtin_amdgcn_ds_bpermute(own << 2, __float_as_int(oz)));
+            float th = inf;
+            if (valid) {
+                const int id = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3));
+                const float4* p = m.tri_rec + (size_t)id * 3;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                float b2 = max_dist;
+                int32_t f2 = -1;
+                vertical_tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, __float_as_int(q2.y), rx, ry, rz, flip, Sz, b2, f2);
+                if (f2 >= 0) th = b2;
+            }
+            // minimum over the four lanes of a slot, then the owner fetches it from the slot's first lane
+            th = fminf(th, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, __float_as_int(th))));
+            th = fminf(th, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, __float_as_int(th))));
+            const float got = __int_as_float(__builtin_amdgcn_ds_bpermute(in_round ? (rank - base) << 4 : lane << 2, __float_as_int(th)));
+            if (in_round) mine = got;
+        }
+        if (owner) {
+            take_hit(mine, 0, best, face);  // (+inf = no hit: refused by t < best / t <= best against max_dist)
+            if (gc.count > 4) vertical_list(m, gc.first + 4, gc.first + gc.count, ox, oy, oz, flip, Sz, dz, best, face);
+        }
+    }
+    if (active && (nbx | nby) && !settled) {  // within tau of a cell boundary the surface is not known to continue across: the neighbouring cells as well
         if (nbx) vertical_cell(m, ix + nbx, iy, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
         if (nby) vertical_cell(m, ix, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);
         if (nbx && nby) vertical_cell(m, ix + nbx, iy + nby, ox, oy, oz, flip, Sz, dz, false, 0, best, face);

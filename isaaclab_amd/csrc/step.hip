@@ -920,13 +920,30 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         const float* __restrict__ ray_local = reinterpret_cast<const float*>(W + P.ray_off);
         const float yw = es[16], yz = es[17];
         const int j = role * 64 + (int)threadIdx.x;  // one ray per lane
-        if (j >= P.R) return;
+        const bool has = j < P.R;  // (no early exit: the wave casts together, see cast_ray_vertical_wave)
         // per-env bases are wave-uniform (scalar); the lane adds a 32-bit column offset
         float* __restrict__ obs_row = Bf.obs + e * D;
         float* __restrict__ hitz_row = P.scan_stateful ? Bf.scan_hit_z + (size_t)e * P.R : nullptr;
-        float hz;
-        if (cast) {
+        float hz = 0.0f;
+        if (cast && !GENERAL_RAYS) {
+            // RayCaster._update_buffers_impl (ray_caster.py:242-260), yaw-aligned sensor, vertical rays: start = yaw(q) * local + sensor pos
+            const float3 l3 = reinterpret_cast<const float3*>(ray_local)[has ? j : P.R - 1];
+            float sx, sy, sz, t = 0.0f;
+            quat_apply_yaw_only(yw, yz, l3.x, l3.y, l3.z, sx, sy, sz);
+            sx += px; sy += py; sz += pz;
+            const bool hit = cast_ray_vertical_wave(M, has, sx, sy, sz, P.rdz, P.rinv_dz, P.ray_max_dist, t);
+            hz = hit ? sz + t * P.rdz : __builtin_huge_valf();  // kernels.py:69
+            if (ray_hits_out && has) {
+                float* o = ray_hits_out + ((size_t)e * P.R + j) * 3;
+                o[0] = hit ? sx + t * P.rdx : __builtin_huge_valf();
+                o[1] = hit ? sy + t * P.rdy : __builtin_huge_valf();
+                o[2] = hz;
+            }
+        } else if (cast && has) {
             hz = scan_ray<GENERAL_RAYS>(P, M, es, ray_local, j, px, py, pz, yw, yz, ray_hits_out, e);
+        }
+        if (!has) return;
+        if (cast) {
             if (cache_z) hitz_row[(unsigned)j] = hz;
         } else {
             hz = hitz_row[(unsigned)j];  // data.ray_hits_w of the last update
