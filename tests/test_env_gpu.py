@@ -123,6 +123,7 @@ def test_wrapper_surface_and_time_outs():
                                     ("Isaac-Velocity-Flat-Anymal-C-v0", 100_003),
                                     # beyond 8192 envs: the observation kernel's env-major wave order, 32-env groups in the step kernel
                                     ("Isaac-Velocity-Rough-Anymal-C-v0", 12_001),
+                                    ("Isaac-Velocity-Rough-Anymal-C-v0", 20_011),  # ... and 64-env groups beyond 16 384
                                     # ragged / tiny batches: partial waves, a single env, one env past a 64-env block
                                     ("Isaac-Velocity-Rough-Anymal-C-v0", 1), ("Isaac-Velocity-Rough-Anymal-C-v0", 63),
                                     ("Isaac-Velocity-Flat-Anymal-C-v0", 65), ("Isaac-Cartpole-v0", 3)])
