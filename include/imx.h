@@ -433,6 +433,31 @@ int imx_actuator_delayed_pd(int64_t N, int64_t J, int max_delay, int64_t step, c
                             const float* effort_limit_d, const float* lookup_d, int num_lookup, float* computed_effort_d,
                             float* applied_effort_d, imx_stream_t stream);
 
+/* ActuatorNetLSTM.compute (actuators/actuator_net.py:72-104; ANYDRIVE_3_LSTM_ACTUATOR_CFG, isaaclab_assets/robots/anymal.py:45-51,
+ * is the actuator of ANYmal-B/C): network input (pos target - pos, vel) per (env, joint) sample, LSTM stack, dense head, the
+ * DC-motor clip of the torque (DCMotor._clip_effort, actuators/actuator_pd.py:276-286).  The network travels as one packed float
+ * array: per LSTM layer W_ih (4H x in), W_hh (4H x H), b_ih (4H), b_hh (4H) (torch's gate order i, f, g, o; in = 2 for the first
+ * layer, H after), then per dense layer W (out x in), b (out); dense_out_h[k] = width of dense layer k (the last must be 1);
+ * act = activation BETWEEN dense layers (0 identity, 1 softsign, 2 tanh, 3 relu, 4 elu).  hidden_state_d / cell_state_d:
+ * (num_lstm, N*J, H), the reference's sea_hidden_state / sea_cell_state, updated in place (the caller zeroes rows at reset, :65-69).
+ * All other arrays (N,J).  SURVEY 8f row 4. */
+int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hidden, int num_dense, const int32_t* dense_out_h, int act,
+                          const float* weights_d, int64_t num_weights, const float* joint_pos_target_d, const float* joint_pos_d,
+                          const float* joint_vel_d, float* hidden_state_d, float* cell_state_d, float saturation_effort,
+                          const float* effort_limit_d, const float* velocity_limit_d, float* computed_effort_d,
+                          float* applied_effort_d, imx_stream_t stream);
+
+/* ActuatorNetMLP.compute (actuators/actuator_net.py:160-195): the position-error and velocity queues (N, history_length, J) are
+ * rolled by one and topped up in place; the sample of (env, joint) is the entries input_idx_d[0..num_idx) of both queues, scaled
+ * by pos_scale / vel_scale, position block first (vel_first = 0, "pos_vel") or second ("vel_pos"); dense network as above (packed
+ * W, b per layer; first width 2 * num_idx); torque * torque_scale, then the DC-motor clip. */
+int imx_actuator_net_mlp(int64_t N, int64_t J, int num_dense, const int32_t* dense_out_h, int act, const float* weights_d,
+                         int64_t num_weights, int history_length, const int32_t* input_idx_d, int num_idx, float pos_scale,
+                         float vel_scale, float torque_scale, int vel_first, const float* joint_pos_target_d,
+                         const float* joint_pos_d, const float* joint_vel_d, float* pos_error_history_d, float* vel_history_d,
+                         float saturation_effort, const float* effort_limit_d, const float* velocity_limit_d,
+                         float* computed_effort_d, float* applied_effort_d, imx_stream_t stream);
+
 /* rsl_rl EmpiricalNormalization.forward (3rd party v2.3.1, absent): if update != 0 fold the batch (N,D) into the running
  * mean / variance (count, mean, var, std are device buffers; Chan's update with the biased batch variance), then
  * out = (x - mean) / (std + eps).  PARITY UNPINNED.  SURVEY 8f row 3. */

@@ -96,6 +96,10 @@ _SIGNATURES = {
     "imx_articulation_update": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float] + [c_void_p] * 6 + [c_void_p]),
     "imx_actuator_pd": (c_int, [c_int64, c_int64, c_int, c_float] + [c_void_p] * 11 + [c_void_p]),
     "imx_actuator_delayed_pd": (c_int, [c_int64, c_int64, c_int, c_int64] + [c_void_p] * 12 + [c_int] + [c_void_p] * 2 + [c_void_p]),
+    "imx_actuator_net_lstm": (c_int, [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64] + [c_void_p] * 5 + [c_float]
+                              + [c_void_p] * 4 + [c_void_p]),
+    "imx_actuator_net_mlp": (c_int, [c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_float, c_float,
+                                     c_float, c_int] + [c_void_p] * 5 + [c_float] + [c_void_p] * 4 + [c_void_p]),
     "imx_empirical_normalization": (c_int, [c_int64, c_int64, c_void_p, c_int, c_float] + [c_void_p] * 5 + [c_void_p]),
     "imx_reset_events": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_uint64, c_void_p] + [c_void_p] * 4
                          + [c_void_p]),

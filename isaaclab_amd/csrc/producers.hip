@@ -425,3 +425,213 @@ extern "C" int imx_actuator_delayed_pd(int64_t N, int64_t J, int max_delay, int6
     IMX_HIP(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ActuatorNetLSTM / ActuatorNetMLP .compute (actuators/actuator_net.py:29-104, 107-195): the learned actuator models of ANYmal
+// (ANYDRIVE_3_LSTM_ACTUATOR_CFG is the actuator of the Anymal-C task robot).  The reference evaluates a TorchScript network on
+// (N*J, ...) inputs; here one lane = one (env, joint) pair carries its sample through the whole network -- LSTM stack + MLP head, or
+// the history MLP -- with the weights staged once per workgroup in LDS (every lane reads the same weight: broadcast) and the
+// lane's activation vectors in LDS columns (lane-minor: conflict-free, dynamically indexable, any layer width up to 64).
+//
+// Packed network (floats), written by isaaclab_amd/producers.py:
+//   LSTM layer l (in_0 = 2, in_l = H): W_ih (4H x in_l) row-major, W_hh (4H x H), b_ih (4H), b_hh (4H); gate rows i, f, g, o (torch)
+//   dense layer k: W (out_k x in_k) row-major, b (out_k); `act` between the dense layers, none after the last
+struct ImxNetDesc {
+    int num_lstm, hidden, num_dense, act;  // act: 0 identity 1 softsign 2 tanh 3 relu 4 elu
+    int dense_out[4];
+    int num_weights;
+};
+#define IMX_NET_MAXW 64
+IMX_DEV float net_act(float x, int act) {
+    switch (act) {
+        case 1: return x / (1.0f + fabsf(x));
+        case 2: return tanhf(x);
+        case 3: return fmaxf(x, 0.0f);
+        case 4: return x > 0.0f ? x : expm1f(x);
+        default: return x;
+    }
+}
+IMX_DEV float net_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// dense layers on the lane's vector in column `va` (in_dim entries) -> result in va again (vb is scratch); returns the last width
+IMX_DEV int net_dense(const ImxNetDesc& D, const float* __restrict__ w, int in_dim, float* va, float* vb, int lane) {
+    for (int k = 0; k < D.num_dense; ++k) {
+        const int out_dim = D.dense_out[k];
+        const float* W = w;
+        const float* b = w + (size_t)out_dim * in_dim;
+        for (int j = 0; j < out_dim; ++j) {
+            float acc = 0.0f;
+            for (int q = 0; q < in_dim; ++q) acc += W[j * in_dim + q] * va[q * 64 + lane];
+            acc += b[j];
+            vb[j * 64 + lane] = k + 1 < D.num_dense ? net_act(acc, D.act) : acc;
+        }
+        for (int j = 0; j < out_dim; ++j) va[j * 64 + lane] = vb[j * 64 + lane];
+        w = b + out_dim;
+        in_dim = out_dim;
+    }
+    return in_dim;
+}
+
+IMX_DEV float dc_motor_clip(float c, float v, float saturation, float elim, float vlim) {  // DCMotor._clip_effort (actuator_pd.py:276-286)
+    const float r = v / vlim;
+    const float hi = fminf(fmaxf(saturation * (1.0f - r), 0.0f), elim);
+    const float lo = fminf(fmaxf(saturation * (-1.0f - r), -elim), 0.0f);
+    return fminf(fmaxf(c, lo), hi);
+}
+
+__global__ void __launch_bounds__(64)
+k_actuator_net_lstm(int64_t n, ImxNetDesc D, const float* __restrict__ weights, const float* __restrict__ q_des, const float* __restrict__ q,
+                    const float* __restrict__ qd, float* __restrict__ hid, float* __restrict__ cell, float saturation,
+                    const float* __restrict__ elim, const float* __restrict__ vlim, float* __restrict__ computed, float* __restrict__ applied) {
+    extern __shared__ float s_net[];
+    float* s_w = s_net;                          // the packed network
+    float* va = s_net + ((D.num_weights + 3) & ~3);  // lane vectors: IMX_NET_MAXW x 64 each
+    float* vb = va + IMX_NET_MAXW * 64;
+    float* vh = vb + IMX_NET_MAXW * 64;          // previous hidden state of the layer
+    const int lane = threadIdx.x;
+    for (int k = lane; k < D.num_weights; k += 64) s_w[k] = weights[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    if (i >= n) return;
+    const int H = D.hidden;
+    const float vel = qd[i];
+    va[lane] = q_des[i] - q[i];  // sea_input[:, 0, 0] = pos error, [:, 0, 1] = joint velocity (:77-78)
+    va[64 + lane] = vel;
+    const float* w = s_w;
+    int in_dim = 2;
+    for (int l = 0; l < D.num_lstm; ++l) {
+        const float* W_ih = w;
+        const float* W_hh = W_ih + (size_t)4 * H * in_dim;
+        const float* b_ih = W_hh + (size_t)4 * H * H;
+        const float* b_hh = b_ih + 4 * H;
+        float* hs = hid + ((size_t)l * n + i) * H;   // (num_layers, N*J, H), the reference's layout
+        float* cs = cell + ((size_t)l * n + i) * H;
+        for (int k = 0; k < H; ++k) vh[k * 64 + lane] = hs[k];
+        for (int k = 0; k < H; ++k) {
+            float g4[4];
+#pragma unroll
+            for (int gI = 0; gI < 4; ++gI) {  // gates i, f, g, o of unit k: linear(input) + linear(hidden) (torch's LSTM cell)
+                const int r = gI * H + k;
+                float a = 0.0f, b = 0.0f;
+                for (int qn = 0; qn < in_dim; ++qn) a += W_ih[r * in_dim + qn] * va[qn * 64 + lane];
+                for (int qn = 0; qn < H; ++qn) b += W_hh[r * H + qn] * vh[qn * 64 + lane];
+                g4[gI] = (a + b_ih[r]) + (b + b_hh[r]);
+            }
+            const float c_new = net_sigmoid(g4[1]) * cs[k] + net_sigmoid(g4[0]) * tanhf(g4[2]);
+            const float h_new = net_sigmoid(g4[3]) * tanhf(c_new);
+            cs[k] = c_new;
+            vb[k * 64 + lane] = h_new;
+        }
+        for (int k = 0; k < H; ++k) {
+            const float h_new = vb[k * 64 + lane];
+            hs[k] = h_new;
+            va[k * 64 + lane] = h_new;  // input of the next layer / of the head
+        }
+        w = b_hh + 4 * H;
+        in_dim = H;
+    }
+    net_dense(D, w, in_dim, va, vb, lane);
+    const float c = va[lane];
+    computed[i] = c;
+    applied[i] = dc_motor_clip(c, vel, saturation, elim[i], vlim[i]);
+}
+
+// ActuatorNetMLP: the (N, history, J) queues of position error and velocity are rolled by one and topped up (:164-170); the inputs of
+// sample (env, joint) are the entries `input_idx` of both queues, scaled, position block first or second (:172-188).
+__global__ void __launch_bounds__(64)
+k_actuator_net_mlp(int64_t N, int J, ImxNetDesc D, const float* __restrict__ weights, int hist, const int32_t* __restrict__ input_idx,
+                   int num_idx, float pos_scale, float vel_scale, float torque_scale, int vel_first, const float* __restrict__ q_des,
+                   const float* __restrict__ q, const float* __restrict__ qd, float* __restrict__ pos_hist, float* __restrict__ vel_hist,
+                   float saturation, const float* __restrict__ elim, const float* __restrict__ vlim, float* __restrict__ computed,
+                   float* __restrict__ applied) {
+    extern __shared__ float s_net[];
+    float* s_w = s_net;
+    float* va = s_net + ((D.num_weights + 3) & ~3);
+    float* vb = va + IMX_NET_MAXW * 64;
+    const int lane = threadIdx.x;
+    for (int k = lane; k < D.num_weights; k += 64) s_w[k] = weights[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    if (i >= N * J) return;
+    const int64_t e = i / J;
+    const int j = (int)(i - e * J);
+    const float vel = qd[i];
+    float* ph = pos_hist + (size_t)e * hist * J + j;  // (N, history, J): entry h of this joint at ph[h * J]
+    float* vh = vel_hist + (size_t)e * hist * J + j;
+    for (int h = hist - 1; h >= 1; --h) { ph[(size_t)h * J] = ph[(size_t)(h - 1) * J]; vh[(size_t)h * J] = vh[(size_t)(h - 1) * J]; }
+    ph[0] = q_des[i] - q[i];
+    vh[0] = vel;
+    for (int k = 0; k < num_idx; ++k) {
+        const int h = input_idx[k];
+        const float p = ph[(size_t)h * J] * pos_scale, v = vh[(size_t)h * J] * vel_scale;
+        va[((vel_first ? num_idx : 0) + k) * 64 + lane] = p;
+        va[((vel_first ? 0 : num_idx) + k) * 64 + lane] = v;
+    }
+    net_dense(D, s_w, 2 * num_idx, va, vb, lane);
+    const float c = va[lane] * torque_scale;
+    computed[i] = c;
+    applied[i] = dc_motor_clip(c, vel, saturation, elim[i], vlim[i]);
+}
+
+static int check_net(const char* who, int num_lstm, int hidden, int num_dense, const int32_t* dense_out, int act, int first_in,
+                     int64_t num_weights, ImxNetDesc& D) {
+    IMX_REQUIRE(num_lstm >= 0 && num_lstm <= 8 && num_dense >= 1 && num_dense <= 4 && act >= 0 && act <= 4, "%s: unsupported network (LSTM layers %d, dense layers %d, activation %d)", who, num_lstm, num_dense, act);
+    IMX_REQUIRE(num_lstm == 0 || (hidden >= 1 && hidden <= IMX_NET_MAXW), "%s: hidden size %d (1..%d)", who, hidden, IMX_NET_MAXW);
+    int64_t need = 0;
+    int in_dim = first_in;
+    for (int l = 0; l < num_lstm; ++l) { need += (int64_t)4 * hidden * (in_dim + hidden) + 8 * hidden; in_dim = hidden; }
+    IMX_REQUIRE(in_dim >= 1 && in_dim <= IMX_NET_MAXW, "%s: input width %d (1..%d)", who, in_dim, IMX_NET_MAXW);
+    for (int k = 0; k < num_dense; ++k) {
+        IMX_REQUIRE(dense_out && dense_out[k] >= 1 && dense_out[k] <= IMX_NET_MAXW, "%s: dense layer %d width out of range (1..%d)", who, k, IMX_NET_MAXW);
+        need += (int64_t)dense_out[k] * in_dim + dense_out[k];
+        in_dim = dense_out[k];
+        D.dense_out[k] = dense_out[k];
+    }
+    IMX_REQUIRE(in_dim == 1, "%s: the last dense layer must have one output (the torque), not %d", who, in_dim);
+    IMX_REQUIRE(need == num_weights, "%s: the packed network holds %lld floats, the layer sizes need %lld", who, (long long)num_weights, (long long)need);
+    IMX_REQUIRE((size_t)(((num_weights + 3) & ~3) + 3 * IMX_NET_MAXW * 64) * sizeof(float) <= 160 * 1024, "%s: network too large for one workgroup's LDS (%lld weights)", who, (long long)num_weights);
+    D.num_lstm = num_lstm; D.hidden = hidden; D.num_dense = num_dense; D.act = act; D.num_weights = (int)num_weights;
+    return 0;
+}
+
+extern "C" int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hidden, int num_dense, const int32_t* dense_out_h, int act,
+                                     const float* weights_d, int64_t num_weights, const float* joint_pos_target_d, const float* joint_pos_d,
+                                     const float* joint_vel_d, float* hidden_state_d, float* cell_state_d, float saturation_effort,
+                                     const float* effort_limit_d, const float* velocity_limit_d, float* computed_effort_d,
+                                     float* applied_effort_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && J > 0 && weights_d && joint_pos_target_d && joint_pos_d && joint_vel_d && hidden_state_d && cell_state_d &&
+                    effort_limit_d && velocity_limit_d && computed_effort_d && applied_effort_d, "imx_actuator_net_lstm: bad arguments");
+    IMX_REQUIRE(num_lstm >= 1, "imx_actuator_net_lstm: no LSTM layer");
+    ImxNetDesc D{};
+    if (check_net("imx_actuator_net_lstm", num_lstm, hidden, num_dense, dense_out_h, act, 2, num_weights, D)) return 1;
+    const int64_t n = N * J;
+    const size_t lds = (size_t)(((num_weights + 3) & ~3) + 3 * IMX_NET_MAXW * 64) * sizeof(float);
+    IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_actuator_net_lstm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_actuator_net_lstm, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, n, D, weights_d,
+                       joint_pos_target_d, joint_pos_d, joint_vel_d, hidden_state_d, cell_state_d, saturation_effort, effort_limit_d,
+                       velocity_limit_d, computed_effort_d, applied_effort_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int imx_actuator_net_mlp(int64_t N, int64_t J, int num_dense, const int32_t* dense_out_h, int act, const float* weights_d,
+                                    int64_t num_weights, int history_length, const int32_t* input_idx_d, int num_idx, float pos_scale,
+                                    float vel_scale, float torque_scale, int vel_first, const float* joint_pos_target_d,
+                                    const float* joint_pos_d, const float* joint_vel_d, float* pos_error_history_d, float* vel_history_d,
+                                    float saturation_effort, const float* effort_limit_d, const float* velocity_limit_d,
+                                    float* computed_effort_d, float* applied_effort_d, imx_stream_t stream) {
+    IMX_REQUIRE(N > 0 && J > 0 && weights_d && input_idx_d && joint_pos_target_d && joint_pos_d && joint_vel_d && pos_error_history_d &&
+                    vel_history_d && effort_limit_d && velocity_limit_d && computed_effort_d && applied_effort_d, "imx_actuator_net_mlp: bad arguments");
+    IMX_REQUIRE(history_length >= 1 && num_idx >= 1 && 2 * num_idx <= IMX_NET_MAXW, "imx_actuator_net_mlp: history %d / %d input indices", history_length, num_idx);
+    ImxNetDesc D{};
+    if (check_net("imx_actuator_net_mlp", 0, 0, num_dense, dense_out_h, act, 2 * num_idx, num_weights, D)) return 1;
+    const int64_t n = N * J;
+    const size_t lds = (size_t)(((num_weights + 3) & ~3) + 2 * IMX_NET_MAXW * 64) * sizeof(float);
+    IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_actuator_net_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_actuator_net_mlp, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, N, (int)J, D, weights_d,
+                       history_length, input_idx_d, num_idx, pos_scale, vel_scale, torque_scale, vel_first, joint_pos_target_d, joint_pos_d,
+                       joint_vel_d, pos_error_history_d, vel_history_d, saturation_effort, effort_limit_d, velocity_limit_d,
+                       computed_effort_d, applied_effort_d);
+    IMX_HIP(hipGetLastError());
+    return 0;
+}

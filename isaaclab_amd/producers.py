@@ -237,3 +237,137 @@ class DelayedPDActuator:
                                             p(self.applied_effort), _lib.current_stream(self.stiffness.device)))
         self.step += 1
         return self.applied_effort
+
+
+_NET_ACT = {"identity": 0, None: 0, "softsign": 1, "tanh": 2, "relu": 3, "elu": 4}
+
+
+def _pack_dense(layers) -> tuple[list[torch.Tensor], list[int]]:
+    """[(weight (out,in), bias (out)), ...] -> flat pieces + widths."""
+    pieces, widths = [], []
+    for w, b in layers:
+        pieces += [w.detach().float().reshape(-1), b.detach().float().reshape(-1)]
+        widths.append(int(w.shape[0]))
+    return pieces, widths
+
+
+def _dense_from_module(net, skip_prefix: str | None) -> list:
+    """The Linear layers of a (TorchScript) network in definition order: every 2-D ``*.weight`` with its ``*.bias``."""
+    sd = net.state_dict()
+    layers = []
+    for name, w in sd.items():
+        if name.endswith("weight") and w.dim() == 2 and not (skip_prefix and name.startswith(skip_prefix)):
+            layers.append((w, sd[name[: -len("weight")] + "bias"]))
+    if not layers:
+        raise ValueError("no Linear layers found in the actuator network")
+    return layers
+
+
+class ActuatorNetLSTM:
+    """``ActuatorNetLSTM.reset`` / ``.compute`` on libimx (reference isaaclab/actuators/actuator_net.py:29-104; the ANYdrive 3 actuator
+    of ANYmal-B/C, isaaclab_assets/robots/anymal.py:45-51): every (env, joint) sample runs through the LSTM stack and the dense head
+    in one launch; hidden and cell states live in ``sea_hidden_state`` / ``sea_cell_state`` (num_layers, N*J, H) like the reference's.
+
+    ``network``: the reference's TorchScript module (``network.lstm`` = ``nn.LSTM(2, H, L, batch_first=True)``, the remaining Linear
+    layers = the head, ``head_activation`` between them) or ``None`` with ``lstm_layers`` = [(w_ih, w_hh, b_ih, b_hh), ...] and
+    ``head`` = [(weight, bias), ...] given directly."""
+
+    def __init__(self, num_envs: int, num_joints: int, effort_limit, velocity_limit, saturation_effort: float, network=None,
+                 lstm_layers=None, head=None, head_activation: str | None = "softsign", device="cuda:0"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("ActuatorNetLSTM needs a GPU: libimx has no CPU path")
+        if network is not None:
+            sd = network.lstm.state_dict()
+            L = len(sd) // 4  # actuator_net.py:54
+            lstm_layers = [(sd[f"weight_ih_l{k}"], sd[f"weight_hh_l{k}"], sd[f"bias_ih_l{k}"], sd[f"bias_hh_l{k}"]) for k in range(L)]
+            head = _dense_from_module(network, "lstm.")
+        if not lstm_layers or not head:
+            raise ValueError("ActuatorNetLSTM needs a network (or lstm_layers and head)")
+        self.num_envs, self.num_joints = int(num_envs), int(num_joints)
+        self.hidden_dim = int(lstm_layers[0][1].shape[1])
+        self.num_layers = len(lstm_layers)
+        pieces = []
+        for w_ih, w_hh, b_ih, b_hh in lstm_layers:
+            pieces += [t.detach().float().reshape(-1) for t in (w_ih, w_hh, b_ih, b_hh)]
+        hp, self._dense_out = _pack_dense(head)
+        self._weights = torch.cat(pieces + hp).to(dev).contiguous()
+        self._dense_arr = (ctypes.c_int32 * len(self._dense_out))(*self._dense_out)
+        self._act = _NET_ACT[head_activation]
+        full = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev).expand(self.num_envs, self.num_joints).contiguous()  # noqa: E731
+        self.effort_limit, self.velocity_limit = full(effort_limit), full(velocity_limit)
+        self.saturation_effort = float(saturation_effort)
+        n = self.num_envs * self.num_joints
+        self.sea_hidden_state = torch.zeros(self.num_layers, n, self.hidden_dim, device=dev)
+        self.sea_cell_state = torch.zeros(self.num_layers, n, self.hidden_dim, device=dev)
+        shape = (self.num_layers, self.num_envs, self.num_joints, self.hidden_dim)
+        self.sea_hidden_state_per_env = self.sea_hidden_state.view(shape)
+        self.sea_cell_state_per_env = self.sea_cell_state.view(shape)
+        self.computed_effort = torch.zeros(self.num_envs, self.num_joints, device=dev)
+        self.applied_effort = torch.zeros(self.num_envs, self.num_joints, device=dev)
+
+    def reset(self, env_ids=None):
+        ids = slice(None) if env_ids is None else env_ids
+        self.sea_hidden_state_per_env[:, ids] = 0.0
+        self.sea_cell_state_per_env[:, ids] = 0.0
+
+    def compute(self, joint_pos_target, joint_pos, joint_vel):
+        p = _lib.ptr
+        check(lib().imx_actuator_net_lstm(self.num_envs, self.num_joints, self.num_layers, self.hidden_dim, len(self._dense_out),
+                                          self._dense_arr, self._act, p(self._weights), self._weights.numel(), p(joint_pos_target),
+                                          p(joint_pos), p(joint_vel), p(self.sea_hidden_state), p(self.sea_cell_state),
+                                          self.saturation_effort, p(self.effort_limit), p(self.velocity_limit), p(self.computed_effort),
+                                          p(self.applied_effort), _lib.current_stream(self._weights.device)))
+        return self.applied_effort
+
+
+class ActuatorNetMLP:
+    """``ActuatorNetMLP.reset`` / ``.compute`` on libimx (reference isaaclab/actuators/actuator_net.py:107-195): the position-error and
+    velocity histories (N, history, J) are rolled and topped up, the ``input_idx`` entries of both scaled and stacked per
+    (env, joint) sample, the dense network evaluated and its torque clipped by the DC-motor model -- one launch.
+    ``network``: the TorchScript module (its Linear layers in order, ``activation`` between them) or ``None`` with ``layers`` given."""
+
+    def __init__(self, num_envs: int, num_joints: int, effort_limit, velocity_limit, saturation_effort: float, input_idx, pos_scale: float,
+                 vel_scale: float, torque_scale: float, input_order: str = "pos_vel", network=None, layers=None,
+                 activation: str | None = "softsign", device="cuda:0"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("ActuatorNetMLP needs a GPU: libimx has no CPU path")
+        if input_order not in ("pos_vel", "vel_pos"):  # actuator_net.py:186-189
+            raise ValueError(f"Invalid input order for MLP actuator net: {input_order}. Must be 'pos_vel' or 'vel_pos'.")
+        if network is not None:
+            layers = _dense_from_module(network, None)
+        if not layers:
+            raise ValueError("ActuatorNetMLP needs a network (or layers)")
+        self.num_envs, self.num_joints = int(num_envs), int(num_joints)
+        self.input_idx = [int(i) for i in input_idx]
+        self.history_length = max(self.input_idx) + 1  # :145
+        pieces, self._dense_out = _pack_dense(layers)
+        self._weights = torch.cat(pieces).to(dev).contiguous()
+        self._dense_arr = (ctypes.c_int32 * len(self._dense_out))(*self._dense_out)
+        self._act = _NET_ACT[activation]
+        self._idx = torch.tensor(self.input_idx, dtype=torch.int32, device=dev)
+        self.pos_scale, self.vel_scale, self.torque_scale = float(pos_scale), float(vel_scale), float(torque_scale)
+        self._vel_first = int(input_order == "vel_pos")
+        full = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev).expand(self.num_envs, self.num_joints).contiguous()  # noqa: E731
+        self.effort_limit, self.velocity_limit = full(effort_limit), full(velocity_limit)
+        self.saturation_effort = float(saturation_effort)
+        self._joint_pos_error_history = torch.zeros(self.num_envs, self.history_length, self.num_joints, device=dev)
+        self._joint_vel_history = torch.zeros(self.num_envs, self.history_length, self.num_joints, device=dev)
+        self.computed_effort = torch.zeros(self.num_envs, self.num_joints, device=dev)
+        self.applied_effort = torch.zeros(self.num_envs, self.num_joints, device=dev)
+
+    def reset(self, env_ids=None):
+        ids = slice(None) if env_ids is None else env_ids
+        self._joint_pos_error_history[ids] = 0.0
+        self._joint_vel_history[ids] = 0.0
+
+    def compute(self, joint_pos_target, joint_pos, joint_vel):
+        p = _lib.ptr
+        check(lib().imx_actuator_net_mlp(self.num_envs, self.num_joints, len(self._dense_out), self._dense_arr, self._act, p(self._weights),
+                                         self._weights.numel(), self.history_length, p(self._idx), len(self.input_idx), self.pos_scale,
+                                         self.vel_scale, self.torque_scale, self._vel_first, p(joint_pos_target), p(joint_pos), p(joint_vel),
+                                         p(self._joint_pos_error_history), p(self._joint_vel_history), self.saturation_effort,
+                                         p(self.effort_limit), p(self.velocity_limit), p(self.computed_effort), p(self.applied_effort),
+                                         _lib.current_stream(self._weights.device)))
+        return self.applied_effort

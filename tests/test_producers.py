@@ -383,3 +383,99 @@ def test_delayed_and_remotized_actuator_hip_matches_reference():
     assert int(act.time_lags.min()) >= 1 and int(act.time_lags.max()) <= 3
     with pytest.raises(ValueError):
         DelayedPDActuator(c_("stiffness"), c_("damping"), 3, 1)
+
+
+# ---- ActuatorNetLSTM / ActuatorNetMLP (the ANYdrive-3 LSTM is the actuator of the Anymal-C task robot): fixture from
+# the REAL classes driving synthetic TorchScript networks (oracle/gen_golden_actuator_nets.py)
+ZN = np.load(os.path.join(GOLDEN, "actuator_nets.npz"))
+
+
+def tn(key):
+    return torch.from_numpy(np.ascontiguousarray(ZN[key]))
+
+
+def _net_layers():
+    lstm = [(tn(f"lstm/net/lstm.weight_ih_l{k}"), tn(f"lstm/net/lstm.weight_hh_l{k}"), tn(f"lstm/net/lstm.bias_ih_l{k}"),
+             tn(f"lstm/net/lstm.bias_hh_l{k}")) for k in range(2)]
+    head = [(tn("lstm/net/fc1.weight"), tn("lstm/net/fc1.bias")), (tn("lstm/net/fc2.weight"), tn("lstm/net/fc2.bias"))]
+    mlp = [(tn(f"mlp/net/{k}.weight"), tn(f"mlp/net/{k}.bias")) for k in (0, 2, 4)]
+    return lstm, head, mlp
+
+
+def _drive_nets(make, tol):
+    m = json.loads(str(ZN["meta"]))
+    lstm, head, mlp = _net_layers()
+    for tag in ("lstm", "mlp"):
+        a, dev = make(tag, m, lstm, head, mlp)
+        for k in range(m["steps"]):
+            if f"{tag}/step{k}/reset_ids" in ZN:
+                a.reset(tn(f"{tag}/step{k}/reset_ids").to(dev))
+            out = a.compute(tn(f"{tag}/step{k}/q_des").to(dev), tn(f"{tag}/step{k}/q").to(dev), tn(f"{tag}/step{k}/qd").to(dev))
+            computed, applied = out if isinstance(out, tuple) else (a.computed_effort, a.applied_effort)
+            assert_close(computed, tn(f"{tag}/step{k}/computed"), tol, f"{tag} step {k} computed effort")
+            assert_close(applied, tn(f"{tag}/step{k}/applied"), tol, f"{tag} step {k} applied effort")
+        yield tag, a
+
+
+def test_actuator_net_oracle_matches_reference():
+    from oracle.producers_oracle import ActuatorNetLSTMOracle, ActuatorNetMLPOracle
+
+    def make(tag, m, lstm, head, mlp):
+        if tag == "lstm":
+            return ActuatorNetLSTMOracle(m["N"], m["J"], lstm, head, "softsign", m["saturation_effort"], m["effort_limit"], m["velocity_limit"]), "cpu"
+        c = m["mlp"]
+        return ActuatorNetMLPOracle(m["N"], m["J"], mlp, c["activation"], c["input_idx"], c["pos_scale"], c["vel_scale"], c["torque_scale"],
+                                    c["input_order"], m["saturation_effort"], m["effort_limit"], m["velocity_limit"]), "cpu"
+
+    # (1e-5: torch's fused LSTM cell and this gate-by-gate restatement round the 10- and 16-term dot products in different orders)
+    for tag, a in _drive_nets(make, 1e-5):
+        if tag == "lstm":
+            assert_close(a.h, tn("lstm/final_hidden"), 1e-5, "hidden state")
+            assert_close(a.c, tn("lstm/final_cell"), 1e-5, "cell state")
+        else:
+            assert_close(a.pos_hist, tn("mlp/final_pos_hist"), 0.0, "position-error history")
+
+
+@pytest.mark.gpu
+def test_actuator_net_hip_matches_reference():
+    """One launch per compute(): LSTM stack + head (or the history MLP) + DC-motor clip for every (env, joint) sample, 8 steps with
+    partial resets, against what the real ActuatorNetLSTM / ActuatorNetMLP computed with the same networks."""
+    from isaaclab_amd.producers import ActuatorNetLSTM, ActuatorNetMLP
+
+    def make(tag, m, lstm, head, mlp):
+        if tag == "lstm":
+            return ActuatorNetLSTM(m["N"], m["J"], m["effort_limit"], m["velocity_limit"], m["saturation_effort"], lstm_layers=lstm, head=head,
+                                   head_activation="softsign"), "cuda:0"
+        c = m["mlp"]
+        return ActuatorNetMLP(m["N"], m["J"], m["effort_limit"], m["velocity_limit"], m["saturation_effort"], c["input_idx"], c["pos_scale"],
+                              c["vel_scale"], c["torque_scale"], c["input_order"], layers=mlp, activation=c["activation"]), "cuda:0"
+
+    for tag, a in _drive_nets(make, 1e-5):
+        if tag == "lstm":
+            assert_close(a.sea_hidden_state, tn("lstm/final_hidden"), 1e-5, "hidden state")
+            assert_close(a.sea_cell_state, tn("lstm/final_cell"), 1e-5, "cell state")
+        else:
+            assert_close(a._joint_pos_error_history, tn("mlp/final_pos_hist"), 0.0, "position-error history")
+            assert_close(a._joint_vel_history, tn("mlp/final_vel_hist"), 0.0, "velocity history")
+    # the TorchScript route of the constructor: layers read out of a scripted module like the reference's
+    import torch.nn as nn
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lstm = nn.LSTM(2, 8, 2, batch_first=True)
+            self.fc1, self.act, self.fc2 = nn.Linear(8, 16), nn.Softsign(), nn.Linear(16, 1)
+
+        def forward(self, x: torch.Tensor, hc: tuple[torch.Tensor, torch.Tensor]):
+            y, (h, c) = self.lstm(x, hc)
+            return self.fc2(self.act(self.fc1(y[:, -1]))), (h, c)
+
+    torch.manual_seed(3)
+    net = torch.jit.script(Net())
+    a = ActuatorNetLSTM(16, 12, 80.0, 7.5, 120.0, network=net)
+    q_des, q, qd = (torch.randn(16, 12, device="cuda:0") for _ in range(3))
+    got = a.compute(q_des, q, qd).cpu()
+    x = torch.stack([(q_des - q).flatten(), qd.flatten()], 1).cpu().unsqueeze(1)
+    ref, _ = net(x, (torch.zeros(2, 192, 8), torch.zeros(2, 192, 8)))
+    assert_close(a.computed_effort, ref.reshape(16, 12), 1e-5, "scripted module")
+    assert torch.isfinite(got).all()
