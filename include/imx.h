@@ -73,6 +73,10 @@ enum imx_rec_word {
 /* a height_scan record that reuses the ray hits of an earlier height_scan record (IMX_R_AUX0 = that record's index), e.g. the
  * "critic" group scanning the same sensor as "policy": one cast per ray and step, as the reference's lazily updated sensor. */
 #define IMX_F_SCAN_TWIN 128
+/* the noise of the term is gaussian_noise (utils/noise/noise_model.py:71-94): NOISE_LO = mean, NOISE_HI = std, combined by the ADD / SCALE / ABS bit;
+ * samples: the fed array holds the reference's randn draws, else an in-kernel Box-Muller pair of the counter-based uniforms.
+ * (constant_noise, :17-39, needs no flag: a uniform noise with NOISE_LO = NOISE_HI = bias is bit-identical) */
+#define IMX_F_NOISE_GAUSS 1024
 enum imx_mod_op {            /* utils/modifiers/modifier.py */
     IMX_M_SCALE = 1,         /* :22-32   a = multiplier */
     IMX_M_BIAS,              /* :49-60   a = value */

@@ -280,7 +280,7 @@ static int parse_plan(const int32_t* blob, size_t nwords, imx_plan* p) {
         const int g = group_of_col(c);
         const size_t ro = (size_t)p->obs_off + (size_t)k * IMX_REC_WORDS;
         int32_t* x = &xall[(size_t)i * 16];
-        x[0] = c - p->gbase[g]; x[1] = w[ro + IMX_R_OP]; x[2] = j; x[3] = (w[ro + IMX_R_FLAGS] & 0xFF) | (g << 8);
+        x[0] = c - p->gbase[g]; x[1] = w[ro + IMX_R_OP]; x[2] = j; x[3] = (w[ro + IMX_R_FLAGS] & 0xFF) | (g << 8) | (w[ro + IMX_R_FLAGS] & IMX_F_NOISE_GAUSS);
         x[4] = w[ro + IMX_R_P0]; x[5] = w[ro + IMX_R_NOISE_LO]; x[6] = w[ro + IMX_R_NOISE_HI];
         x[7] = w[ro + IMX_R_CLIP_LO]; x[8] = w[ro + IMX_R_CLIP_HI]; x[9] = w[ro + IMX_R_SCALE];
         const int op = x[1];

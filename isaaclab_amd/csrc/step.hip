@@ -672,6 +672,24 @@ IMX_DEV XCol load_xcol(const int32_t* __restrict__ W, int off, int i) {
     return x;
 }
 
+// The noise term of one element: uniform_noise u * (n_max - n_min) + n_min (noise_model.py:62-66; constant_noise is the case n_min == n_max)
+// or gaussian_noise mean + std * z (:87-92).  The sample is the fed one (the reference's recorded rand_like / randn_like draw) or comes
+// from the counter-based generator (Box-Muller on two of its uniforms for z).
+IMX_DEV float noise_sample(int flags, float lo, float hi, const float* __restrict__ noise_u, uint64_t seed, uint32_t step, int64_t e, int D, int c) {
+    if (flags & IMX_F_NOISE_GAUSS) {
+        float z;
+        if (noise_u) {
+            z = noise_u[e * D + c];
+        } else {
+            const float u1 = uniform01(seed, step, (uint64_t)e * D + c), u2 = uniform01(seed ^ 0x6A09E667F3BCC909ull, step, (uint64_t)e * D + c);
+            z = sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.28318530717958647692f * u2);  // 1 - u1 in (0, 1]: no log(0)
+        }
+        return lo + hi * z;
+    }
+    const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
+    return u * (hi - lo) + lo;
+}
+
 // D = width of the whole column space (all groups side by side), gbase = first column of this entry's group in it: the parity-mode
 // uniforms are one (N, D) array, group after group
 IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restrict__ noise_u, uint64_t seed, uint32_t step,
@@ -680,9 +698,8 @@ IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restr
     if (corrupt && (flags & (IMX_F_NOISE_ADD | IMX_F_NOISE_SCALE | IMX_F_NOISE_ABS))) {
         // a term with a history window draws for its first (oldest-slot) columns, like rand_like on the (N, d) term value
         const int c = gbase + x.a.x - (x.d.z - 1) * x.d.w;
-        const float u = noise_u ? noise_u[e * D + c] : uniform01(seed, step, (uint64_t)e * D + c);
         const float lo = f_of(x.b.y), hi = f_of(x.b.z);
-        const float nz = u * (hi - lo) + lo;  // noise_model.py:62-66
+        const float nz = noise_sample(flags, lo, hi, noise_u, seed, step, e, D, c);
         v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
     }
     if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, f_of(x.b.w)), f_of(x.c.x));
@@ -951,8 +968,7 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         float v = pz - hz - off;
         const int c = out + j;
         if (noisy) {
-            const float u = noise_u ? (noise_u + e * P.D)[(unsigned)c] : uniform01(seed, step, (uint64_t)e * P.D + c);
-            const float nz = u * (nhi - nlo) + nlo;  // noise_model.py:62-66
+            const float nz = noise_sample(flags, nlo, nhi, noise_u, seed, step, e, P.D, c);
             v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
         }
         if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);

@@ -35,6 +35,7 @@ H = dict(MAGIC=0, VERSION=1, J=2, B=3, H=4, A=5, D=6, R=7, NTERM=8, NREW=9, NOBS
 R = dict(OP=0, IDS_OFF=1, NIDS=2, IDS2_OFF=3, NIDS2=4, WEIGHT=5, P0=6, P1=7, P2=8, P3=9, OUT=10, DIM=11, FLAGS=12,
          NOISE_LO=13, NOISE_HI=14, CLIP_LO=15, CLIP_HI=16, SCALE=17, AUX0=18, AUX1=19)
 F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE, F_MODIFIERS, F_SCAN_TWIN = 1, 2, 4, 8, 16, 32, 64, 128
+F_NOISE_GAUSS = 1024
 M_OPS = dict(SCALE=1, BIAS=2, CLIP=3, INTEGRATOR=4, DIGITAL_FILTER=5)
 F_ACT_DEFAULT_POS_OFFSET, F_ACT_DEFAULT_VEL_OFFSET, F_ACT_CLIP = 1, 2, 4
 
@@ -624,15 +625,24 @@ class PlanCompiler:
                     if hist > 0:
                         raise NotImplementedError(f"observation term '{name}': history on a term evaluated in Python is not supported")
                 noise = tcfg.get("noise")
-                if noise:  # only the reference's uniform_noise on scalars runs in the kernel; anything else must not be dropped silently
+                if noise:  # the reference's three noise functions with scalar parameters run in the kernel; anything else must not be dropped silently
                     nfn = _short(func_name(noise["func"]))[1]
-                    if nfn != "uniform_noise" or not isinstance(noise.get("n_min"), (int, float)) or not isinstance(noise.get("n_max"), (int, float)):
-                        if grp.enable_corruption:
-                            raise NotImplementedError(f"observation term '{name}': noise model {func_name(noise['func'])} is not on the fused path "
-                                                      "(uniform_noise with scalar bounds is)")
-                    else:
-                        flags |= {"add": F_NOISE_ADD, "scale": F_NOISE_SCALE, "abs": F_NOISE_ABS}[noise.get("operation", "add")]
+                    num = lambda *ks: all(isinstance(noise.get(k_), (int, float)) for k_ in ks)  # noqa: E731
+                    opbit = {"add": F_NOISE_ADD, "scale": F_NOISE_SCALE, "abs": F_NOISE_ABS}.get(noise.get("operation", "add"))
+                    if opbit is None:
+                        raise ValueError(f"Unknown operation in noise: {noise.get('operation')}")  # noise_model.py:38,68,94
+                    if nfn == "uniform_noise" and num("n_min", "n_max"):
+                        flags |= opbit
                         rec.update(noise_lo=f32(noise["n_min"]), noise_hi=f32(noise["n_max"]))
+                    elif nfn == "constant_noise" and num("bias"):  # u * (b - b) + b == b for every u: the uniform path, bit-identical
+                        flags |= opbit
+                        rec.update(noise_lo=f32(noise["bias"]), noise_hi=f32(noise["bias"]))
+                    elif nfn == "gaussian_noise" and num("mean", "std"):
+                        flags |= opbit | F_NOISE_GAUSS
+                        rec.update(noise_lo=f32(noise["mean"]), noise_hi=f32(noise["std"]))
+                    elif grp.enable_corruption:
+                        raise NotImplementedError(f"observation term '{name}': noise model {func_name(noise['func'])} is not on the fused path "
+                                                  "(uniform_noise, constant_noise and gaussian_noise with scalar parameters are)")
                 if tcfg.get("clip") is not None:
                     flags |= F_CLIP
                     rec.update(clip_lo=f32(tcfg["clip"][0]), clip_hi=f32(tcfg["clip"][1]))

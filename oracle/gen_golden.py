@@ -265,7 +265,7 @@ def build_ref_env(env_cfg, robot: RobotSpec, feed: StateFeed, real_scanner=None)
     env.sim = types.SimpleNamespace(is_playing=lambda: True)
     env.cfg = env_cfg
     env.scene = FakeScene({"robot": robot_asset}, sensors, feed["env_origins"], env_cfg.scene)
-    env.scene.terrain = types.SimpleNamespace(cfg=env_cfg.scene.terrain)  # terrain_out_of_bounds reads scene.terrain.cfg.terrain_generator
+    env.scene.terrain = types.SimpleNamespace(cfg=getattr(env_cfg.scene, "terrain", None))  # terrain_out_of_bounds reads scene.terrain.cfg.terrain_generator
     env.common_step_counter = 0
     env.step_dt = env_cfg.sim.dt * env_cfg.decimation
     env.max_episode_length_s = env_cfg.episode_length_s
@@ -366,12 +366,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
     # uniform samples consumed by uniform_noise (observation_manager.py:313 -> noise_model.py:62): recorded so the
     # HIP path can be fed the same draws (torch's CPU RNG stream cannot be reproduced in-kernel).
     real_rand_like = torch.rand_like
+    real_randn_like = torch.randn_like
 
     def compute_obs(tag):
         # the reference computes obs term by term; noisy terms call rand_like in term order.  Columns of `u` are
         # laid out per OBS COLUMN (D wide): advance `col` to each term's offset.
         u = torch.rand(N, D, generator=gen)
-        put(f"{tag}/noise_u", u)
         # term-offset bookkeeping: patch so that draw k lands on the columns of the k-th noisy term (groups side by side, in the
         # order ObservationManager.compute walks them)
         noisy_offsets, base = [], 0
@@ -379,8 +379,14 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
             dims = [int(np.prod(d)) for d in om.group_obs_term_dim[gname]]
             cfgs = om._group_obs_term_cfgs[gname]
             offs = np.concatenate([[0], np.cumsum(dims)])
-            noisy_offsets += [base + int(offs[i]) for i, c in enumerate(cfgs) if c.noise]
+            # (constant_noise draws nothing; gaussian_noise draws with randn_like: its columns of the recorded array hold normal samples)
+            drawing = [(i, c) for i, c in enumerate(cfgs) if c.noise and c.noise.func.__name__ != "constant_noise"]
+            noisy_offsets += [base + int(offs[i]) for i, c in drawing]
+            for i, c in drawing:
+                if c.noise.func.__name__ == "gaussian_noise":
+                    u[:, base + int(offs[i]):base + int(offs[i]) + dims[i]] = torch.randn(N, dims[i], generator=gen)
             base += int(offs[-1])
+        put(f"{tag}/noise_u", u)
         it = iter(noisy_offsets)
 
         def rand_like_at(x, *a, **k):
@@ -388,10 +394,12 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
             return u[:, c0:c0 + x.shape[1]].clone()
 
         ref_noise_model.torch.rand_like = rand_like_at  # same module object as torch; restore below
+        ref_noise_model.torch.randn_like = rand_like_at
         try:
             all_obs = env.observation_manager.compute()
         finally:
             torch.rand_like = real_rand_like
+            torch.randn_like = real_randn_like
         obs = all_obs[group_names[0]]
         put(f"{tag}/obs", obs)
         for gname in group_names[1:]:
@@ -704,6 +712,20 @@ def main():
         stack.velocity_commands = Obs(func=mdp.generated_commands, params={"command_name": "base_velocity"})
         shp_cfg.observations.stack = stack
         run_task("Isaac-Velocity-Flat-Anymal-C-v0-shapes", shp_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=5, seed=108)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0-noise"):
+        # the noise functions besides uniform_noise (utils/noise/noise_model.py:17-39,71-94): constant and gaussian, each with add / scale / abs
+        from isaaclab.utils.noise import ConstantNoiseCfg, GaussianNoiseCfg, UniformNoiseCfg
+
+        nz_cfg = AnymalCFlatEnvCfg()
+        pol = nz_cfg.observations.policy
+        pol.base_lin_vel.noise = GaussianNoiseCfg(mean=0.01, std=0.1)
+        pol.base_ang_vel.noise = ConstantNoiseCfg(bias=0.05)
+        pol.projected_gravity.noise = GaussianNoiseCfg(mean=1.0, std=0.05, operation="scale")
+        pol.velocity_commands.noise = ConstantNoiseCfg(bias=0.25, operation="abs")
+        pol.joint_pos.noise = UniformNoiseCfg(n_min=0.9, n_max=1.1, operation="scale")
+        pol.joint_vel.noise = ConstantNoiseCfg(bias=0.9, operation="scale")
+        pol.actions.noise = GaussianNoiseCfg(mean=-0.2, std=0.3, operation="abs")
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0-noise", nz_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=3, seed=109)
     if want("Isaac-Velocity-Flat-Anymal-C-v0-mod"):
         # observation modifiers (ObservationTermCfg.modifiers; utils/modifiers/modifier.py): stateless chain, IIR/FIR filter,
         # integrator -- on the flat task, 6 steps so that filter/integrator state and its reset are exercised

@@ -165,8 +165,16 @@ def test_observation_modifiers_compile_to_programs_and_the_library_validates_the
         planmod.compile_plan(cfg, g.robot)  # a stateful modifier class behind a foreign one cannot run anywhere
     cfg = copy.deepcopy(g.fixture["env"])
     cfg["observations"]["policy"]["joint_vel"]["noise"] = {"func": "isaaclab.utils.noise.noise_model:gaussian_noise", "mean": 0.0, "std": 1.0, "operation": "add"}
+    assert planmod.compile_plan(cfg, g.robot).enable_corruption  # gaussian / constant / uniform noise with scalar parameters are fused
+    cfg["observations"]["policy"]["joint_vel"]["noise"]["std"] = [1.0] * 12  # per-element parameters are not
     with pytest.raises(NotImplementedError, match="noise model"):
         planmod.compile_plan(cfg, g.robot)  # never dropped silently
+    cfg["observations"]["policy"]["joint_vel"]["noise"] = {"func": "my_pkg.noise:pink_noise", "alpha": 1.0}
+    with pytest.raises(NotImplementedError, match="noise model"):
+        planmod.compile_plan(cfg, g.robot)
+    cfg["observations"]["policy"]["joint_vel"]["noise"] = {"func": "isaaclab.utils.noise.noise_model:constant_noise", "bias": 0.1, "operation": "mul"}
+    with pytest.raises(ValueError, match="Unknown operation in noise"):
+        planmod.compile_plan(cfg, g.robot)  # noise_model.py:38
 
 
 def test_policy_is_exportable_like_the_reference_exporter(tmp_path):
