@@ -264,6 +264,25 @@ def test_in_kernel_noise_is_uniform_and_bounded():
     assert float(d[:, 0:3].abs().max()) <= 0.1 + 1e-6 and float(d[:, 0:3].abs().max()) > 0.05
     assert float(d[:, 9:12].abs().max()) == 0.0
     assert abs(float(d[:, 24:36].mean())) < 0.2  # joint_vel noise U(-1.5,1.5), 768 samples
+    # the gaussian generator (Box-Muller on the counter-based uniforms): actions = N(-0.2, 0.3) ("abs"), base_lin_vel += N(0.01, 0.1),
+    # base_ang_vel += 0.05 (constant_noise draws nothing); 64 envs x 12 / 3 columns x 3 steps of fresh samples
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0-noise")
+    env = make_env(g)
+    env.reset()
+    acts, dl, da = [], [], []
+    for _ in range(6):
+        o = env.step(a)[0]["policy"].clone()
+        env.plan.enable_corruption = False
+        env.feed.seek(env.feed.index)
+        clean = env._compute_observations().clone()
+        env.plan.enable_corruption = True
+        acts.append(o[:, 36:48]); dl.append(o[:, 0:3] - clean[:, 0:3]); da.append(o[:, 3:6] - clean[:, 3:6])
+    z = (torch.cat(acts) + 0.2) / 0.3
+    assert abs(float(z.mean())) < 0.06 and abs(float(z.std()) - 1.0) < 0.05 and float(z.abs().max()) > 2.5  # 4608 samples
+    assert not torch.equal(acts[0], acts[1])  # fresh every step
+    zl = (torch.cat(dl) - 0.01) / 0.1
+    assert abs(float(zl.mean())) < 0.1 and abs(float(zl.std()) - 1.0) < 0.1
+    assert float((torch.cat(da) - 0.05).abs().max()) < 1e-6
 
 
 def test_env_owned_command_term_and_contact_sensor():
