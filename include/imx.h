@@ -88,6 +88,7 @@ enum imx_mod_op {            /* utils/modifiers/modifier.py */
 #define IMX_F_ACT_DEFAULT_POS_OFFSET 1 /* JointPositionAction use_default_offset (joint_actions.py:152-154) */
 #define IMX_F_ACT_DEFAULT_VEL_OFFSET 2 /* JointVelocityAction (joint_actions.py:206-208) */
 #define IMX_F_ACT_CLIP 4
+#define IMX_F_ACT_TO_LIMITS 8 /* JointPositionToLimitsAction rescale_to_limits: clamp(-1, 1), unscale_transform onto soft_joint_pos_limits (joint_actions_to_limits.py:116-126) */
 
 /* termination ops -- envs/mdp/terminations.py */
 enum imx_term_op {

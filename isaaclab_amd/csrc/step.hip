@@ -176,6 +176,11 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
             const float lo = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j]), hi = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j + 1]);
             v = fminf(fmaxf(v, lo), hi);
         }
+        if (flags & IMX_F_ACT_TO_LIMITS) {  // clamp(-1, 1), then unscale_transform (utils/math.py:43-61): x * (upper - lower) * 0.5 + (lower + upper) * 0.5
+            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+            v = v * (lim.y - lim.x) * 0.5f + (lim.x + lim.y) * 0.5f;
+        }
         Bf.processed_action[i] = v;
     }
 }
@@ -1128,6 +1133,7 @@ extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float
         const int flags = plan->host[plan->act_off + k * IMX_REC_WORDS + IMX_R_FLAGS];
         if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) IMX_REQUIRE(st->default_joint_pos, "default_joint_pos missing");
         if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) IMX_REQUIRE(st->default_joint_vel, "default_joint_vel missing");
+        if (flags & IMX_F_ACT_TO_LIMITS) IMX_REQUIRE(st->soft_joint_pos_limits, "soft_joint_pos_limits missing");
     }
     const int64_t n = N * plan->A;
     const int bs = 256;

@@ -465,8 +465,7 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
                 modify_reward_weight(env, torch.arange(N), term_name=wc[1], weight=wc[2], num_steps=5)
         # -- pre-physics
         env.action_manager.process_action(action)
-        term0 = next(iter(env.action_manager._terms.values()))
-        put(f"{tag}/processed_actions", term0.processed_actions)
+        put(f"{tag}/processed_actions", torch.cat([t_.processed_actions for t_ in env.action_manager._terms.values()], dim=1))
         put(f"{tag}/prev_action", env.action_manager.prev_action)
         # -- physics: feed moves to the next snapshot
         feed.advance()
@@ -726,6 +725,19 @@ def main():
         pol.joint_vel.noise = ConstantNoiseCfg(bias=0.9, operation="scale")
         pol.actions.noise = GaussianNoiseCfg(mean=-0.2, std=0.3, operation="abs")
         run_task("Isaac-Velocity-Flat-Anymal-C-v0-noise", nz_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=3, seed=109)
+    if want("Isaac-Velocity-Flat-Anymal-C-v0-actions"):
+        # the other joint action terms (envs/mdp/actions/joint_actions.py:163-193, joint_actions_to_limits.py:25-139) and per-joint
+        # scale / clip dicts: three terms side by side in one ActionManager
+        import isaaclab.envs.mdp as mdp
+
+        act_cfg = AnymalCFlatEnvCfg()
+        del act_cfg.actions.joint_pos
+        act_cfg.actions.haa_rel = mdp.RelativeJointPositionActionCfg(asset_name="robot", joint_names=[".*HAA"], scale=0.3, offset=0.7)
+        act_cfg.actions.hfe_lim = mdp.JointPositionToLimitsActionCfg(asset_name="robot", joint_names=[".*HFE"], scale={".*F_HFE": 0.8, ".*H_HFE": 0.4},
+                                                                      clip={"LF_HFE": (-0.5, 0.25)})
+        act_cfg.actions.kfe_vel = mdp.JointVelocityActionCfg(asset_name="robot", joint_names=[".*KFE"], scale=2.0, use_default_offset=False,
+                                                             offset={"L.*": 0.1, "R.*": -0.1}, clip={"R.*KFE": (-1.5, 1.5)})
+        run_task("Isaac-Velocity-Flat-Anymal-C-v0-actions", act_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=3, seed=110)
     if want("Isaac-Velocity-Flat-Anymal-C-v0-mod"):
         # observation modifiers (ObservationTermCfg.modifiers; utils/modifiers/modifier.py): stateless chain, IIR/FIR filter,
         # integrator -- on the flat task, 6 steps so that filter/integrator state and its reset are exercised

@@ -15,6 +15,7 @@ from isaaclab_amd.state_feed import DYNAMIC, EXTRA, STATIC, StateFeed
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TASKS = ("Isaac-Cartpole-v0", "Isaac-Velocity-Flat-Anymal-C-v0", "Isaac-Velocity-Flat-Anymal-C-v0-hist3", "Isaac-Velocity-Flat-Anymal-C-v0-mod",
          "Isaac-Velocity-Flat-Anymal-C-v0-noise",  # constant_noise / gaussian_noise / uniform_noise x add / scale / abs
+         "Isaac-Velocity-Flat-Anymal-C-v0-actions",  # RelativeJointPosition / JointPositionToLimits / JointVelocity terms, per-joint dicts
          "Isaac-Velocity-Rough-Anymal-C-v0",
          "Isaac-Velocity-Rough-G1-v0")
 FLOAT_TOL = 1e-5  # BASELINE.json north_star: within 1e-5 fp32 on observations, rewards and returns

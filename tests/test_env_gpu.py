@@ -51,7 +51,7 @@ def test_env_step_matches_reference_goldens(task, tail):
             assert torch.equal(env.termination_manager.get_term(name).cpu(), g.t(f"{tag}/term_dones/{name}")), name
         assert torch.equal(env.episode_length_buf.cpu(), g.t(f"{tag}/episode_length_buf")), "episode_length_buf"
         # -- floats
-        assert_close(env.action_manager.get_term(env.action_manager.active_terms[0]).processed_actions,
+        assert_close(torch.cat([env.action_manager.get_term(n).processed_actions for n in env.action_manager.active_terms], dim=1),
                      g.t(f"{tag}/processed_actions"), FLOAT_TOL, "processed_actions")
         assert_close(rew, g.t(f"{tag}/reward"), FLOAT_TOL, "reward")
         assert_close(env.reward_manager._step_reward, g.t(f"{tag}/step_reward"), FLOAT_TOL, "step_reward")
