@@ -680,8 +680,11 @@ IMX_DEV XCol load_xcol(const int32_t* __restrict__ W, int off, int i) {
 // The noise term of one element: uniform_noise u * (n_max - n_min) + n_min (noise_model.py:62-66; constant_noise is the case n_min == n_max)
 // or gaussian_noise mean + std * z (:87-92).  The sample is the fed one (the reference's recorded rand_like / randn_like draw) or comes
 // from the counter-based generator (Box-Muller on two of its uniforms for z).
+// GAUSS = false: plans without a gaussian term (the LEAN kernels: logf / cosf / sqrtf in their instruction stream cost 2 % at 4096 envs
+// and 7 % at 65 536, taken or not; a plan with gaussian noise runs the general kernels).
+template <bool GAUSS>
 IMX_DEV float noise_sample(int flags, float lo, float hi, const float* __restrict__ noise_u, uint64_t seed, uint32_t step, int64_t e, int D, int c) {
-    if (flags & IMX_F_NOISE_GAUSS) {
+    if (GAUSS && (flags & IMX_F_NOISE_GAUSS)) {
         float z;
         if (noise_u) {
             z = noise_u[e * D + c];
@@ -697,6 +700,7 @@ IMX_DEV float noise_sample(int flags, float lo, float hi, const float* __restric
 
 // D = width of the whole column space (all groups side by side), gbase = first column of this entry's group in it: the parity-mode
 // uniforms are one (N, D) array, group after group
+template <bool GAUSS>
 IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restrict__ noise_u, uint64_t seed, uint32_t step,
                        int64_t e, int D, int gbase) {
     const int flags = x.a.w;
@@ -704,7 +708,7 @@ IMX_DEV float obs_post(const XCol& x, float v, int corrupt, const float* __restr
         // a term with a history window draws for its first (oldest-slot) columns, like rand_like on the (N, d) term value
         const int c = gbase + x.a.x - (x.d.z - 1) * x.d.w;
         const float lo = f_of(x.b.y), hi = f_of(x.b.z);
-        const float nz = noise_sample(flags, lo, hi, noise_u, seed, step, e, D, c);
+        const float nz = noise_sample<GAUSS>(flags, lo, hi, noise_u, seed, step, e, D, c);
         v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
     }
     if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, f_of(x.b.w)), f_of(x.c.x));
@@ -833,7 +837,7 @@ IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& 
                         bool fill_all, const float* __restrict__ noise_u, uint64_t seed, uint32_t step) {
     const int c = x.a.x;
     if (LEAN) {
-        Bf.obs[e * P.gD[0] + c] = obs_post(x, v, corrupt & P.gcorrupt, noise_u, seed, step, e, P.D, 0);
+        Bf.obs[e * P.gD[0] + c] = obs_post<false>(x, v, corrupt & P.gcorrupt, noise_u, seed, step, e, P.D, 0);
         return;
     }
     const int g = (x.a.w >> 8) & 3;  // observation group of this column (ObservationManager.compute loops over the groups)
@@ -842,7 +846,7 @@ IMX_DEV void obs_finish(const PlanView& P, const imx_buffers_t& Bf, const XCol& 
     float* grow = g == 0 ? Bf.obs : (g == 1 ? Bf.obs_extra1 : (g == 2 ? Bf.obs_extra2 : Bf.obs_extra3));
     if (x.a.w & IMX_F_MODIFIERS)
         v = apply_modifiers(P.w, P.xmod_off + 4 * i, v, Bf.mod_state + e * P.MS, fill_all || Bf.reset_buf[e]);
-    const float vp = obs_post(x, v, corrupt & (P.gcorrupt >> g), noise_u, seed, step, e, P.D, gb);
+    const float vp = obs_post<true>(x, v, corrupt & (P.gcorrupt >> g), noise_u, seed, step, e, P.D, gb);
     float* o = grow + e * gD + c;  // newest slot
     const int hist = x.d.z;
     if (hist > 1) {
@@ -973,7 +977,7 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         float v = pz - hz - off;
         const int c = out + j;
         if (noisy) {
-            const float nz = noise_sample(flags, nlo, nhi, noise_u, seed, step, e, P.D, c);
+            const float nz = noise_sample<false>(flags, nlo, nhi, noise_u, seed, step, e, P.D, c);
             v = (flags & IMX_F_NOISE_ADD) ? v + nz : ((flags & IMX_F_NOISE_SCALE) ? v * nz : nz);
         }
         if (flags & IMX_F_CLIP) v = fminf(fmaxf(v, clo), chi);
@@ -1274,7 +1278,7 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     const int nlog = plan->nrew_all + plan->nterm;
     // the lean variant: one group, no modifier programs, no history windows (DC == D also rules out twin scan columns)
     bool lean = plan->ngroups == 1 && plan->MS == 0 && plan->DC == plan->D && plan->DX == plan->DC;
-    for (int k = 0; k < plan->nobs && lean; ++k) lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & IMX_F_MODIFIERS);
+    for (int k = 0; k < plan->nobs && lean; ++k) lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & (IMX_F_MODIFIERS | IMX_F_NOISE_GAUSS));
 #define IMX_LAUNCH_OBS(G, L)                                                                                                     \
     hipLaunchKernelGGL((k_obs<G, L>), dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed, \
                        enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts)
