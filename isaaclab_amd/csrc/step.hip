@@ -7,6 +7,13 @@
 // association order (compile with -ffp-contract=off).
 #include "imx_internal.h"
 #include "imx_raycast.h"
+// Scalar-register budget of the lean observation kernel.  On gfx950 a SIMD has 800 SGPRs, allocated in blocks of 16: the 106 the compiler
+// takes by default (100 + VCC / FLAT_SCRATCH / XNACK) round to 112 = SEVEN waves per SIMD although the 57 VGPRs allow eight.  Capped,
+// the compiler parks ~30 rarely used scalars in VGPR lanes; measured at 65 536 envs: 102 -> 142 us, 96 -> 132, 88 -> 132, 80 -> 126,
+// 72 -> 129, 64 -> 135 (at 4096 envs all within 0.2 us).
+#ifndef IMX_LEAN_SGPRS
+#define IMX_LEAN_SGPRS 80
+#endif
 
 // ------------------------------------------------------------------------------------------------- helpers
 IMX_DEV float wave_sum(float v) {
@@ -901,7 +908,7 @@ IMX_DEV float scan_ray(const PlanView& P, const MeshView& M, const float* __rest
 // chip re-fills wave slots after the first residency round (tools/trace_kobs.py): a one-wave workgroup fits any free slot, a four-wave
 // one needs four on one CU.
 template <bool GENERAL_RAYS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(IMX_LEAN_SGPRS)))
 k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, const float* __restrict__ frame,
            const float* __restrict__ noise_u, uint64_t seed, int corrupt, float* __restrict__ ray_hits_out, StepScratch sc, int tail_G,
            int tail_parts, int scan_rec, int waves_per_env, uint32_t div_magic, int div_shift, const int32_t* __restrict__ W) {
