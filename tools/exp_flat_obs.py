@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+if os.environ.get("IMX_EXP_LIB"):
+    from isaaclab_amd import _lib
+    _lib.LIB_PATH = os.path.join("/root/repo", "tools", "libimx_%s.so" % os.environ["IMX_EXP_LIB"])
+import torch
+from bench import build_env
+from tools.exp_obs_util import timeit
+dev = torch.device("cuda:0")
+for N in (4096, 65536):
+    fx, env, _ = build_env("Isaac-Velocity-Flat-Anymal-C-v0", N, dev, 42, 4, (10, 20))
+    env.reset()
+    print("flat task obs N=%d  %.2f us" % (N, timeit(lambda: env._compute_observations(frame_current=True))))
