@@ -88,6 +88,9 @@ enum imx_mod_op {            /* utils/modifiers/modifier.py */
 #define IMX_F_ACT_DEFAULT_POS_OFFSET 1 /* JointPositionAction use_default_offset (joint_actions.py:152-154) */
 #define IMX_F_ACT_DEFAULT_VEL_OFFSET 2 /* JointVelocityAction (joint_actions.py:206-208) */
 #define IMX_F_ACT_CLIP 4
+#define IMX_F_ACT_EMA 16 /* EMAJointPositionToLimitsAction (joint_actions_to_limits.py:142-230): alpha * processed + (1 - alpha) * previous applied action,
+                           clamped to the soft limits; alpha = P1 or the per-joint table AUX1; the previous applied action is processed_action
+                           itself (an env reset in the last step starts from its joint positions, :208-217: reset_buf is read) */
 #define IMX_F_ACT_TO_LIMITS 8 /* JointPositionToLimitsAction rescale_to_limits: clamp(-1, 1), unscale_transform onto soft_joint_pos_limits (joint_actions_to_limits.py:116-126) */
 
 /* termination ops -- envs/mdp/terminations.py */

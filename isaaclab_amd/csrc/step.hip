@@ -178,7 +178,7 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
         const int jid = P.w[r[IMX_R_IDS_OFF] + j];
         if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) offset = S.default_joint_pos[e * P.J + jid];
         if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) offset = S.default_joint_vel[e * P.J + jid];
-        float v = a * scale + offset;
+        float v = (flags & IMX_F_ACT_EMA) ? a * scale : a * scale + offset;  // (an EMA term has no offset: the slot carries alpha)
         if (flags & IMX_F_ACT_CLIP) {
             const float lo = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j]), hi = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j + 1]);
             v = fminf(fmaxf(v, lo), hi);
@@ -187,6 +187,12 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
             const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
             v = fminf(fmaxf(v, -1.0f), 1.0f);
             v = v * (lim.y - lim.x) * 0.5f + (lim.x + lim.y) * 0.5f;
+        }
+        if (flags & IMX_F_ACT_EMA) {  // joint_actions_to_limits.py:219-230
+            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
+            const float prev = (Bf.reset_buf && Bf.reset_buf[e]) ? S.joint_pos[e * P.J + jid] : Bf.processed_action[i];
+            v = offset * v + (1.0f - offset) * prev;
+            v = fminf(fmaxf(v, lim.x), lim.y);
         }
         Bf.processed_action[i] = v;
     }
@@ -1144,7 +1150,8 @@ extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float
         const int flags = plan->host[plan->act_off + k * IMX_REC_WORDS + IMX_R_FLAGS];
         if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) IMX_REQUIRE(st->default_joint_pos, "default_joint_pos missing");
         if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) IMX_REQUIRE(st->default_joint_vel, "default_joint_vel missing");
-        if (flags & IMX_F_ACT_TO_LIMITS) IMX_REQUIRE(st->soft_joint_pos_limits, "soft_joint_pos_limits missing");
+        if (flags & (IMX_F_ACT_TO_LIMITS | IMX_F_ACT_EMA)) IMX_REQUIRE(st->soft_joint_pos_limits, "soft_joint_pos_limits missing");
+        if (flags & IMX_F_ACT_EMA) IMX_REQUIRE(st->joint_pos, "joint_pos missing");
     }
     const int64_t n = N * plan->A;
     const int bs = 256;

@@ -180,6 +180,18 @@ class ActionManager:
         ids = slice(None) if env_ids is None else env_ids
         self._env._prev_action[ids] = 0.0
         self._env._action[ids] = 0.0
+        # EMAJointPositionToLimitsAction.reset (joint_actions_to_limits.py:208-217): the moving average restarts from the joint positions
+        # (inside env.step() the action kernel does this itself for the envs the step kernel reset)
+        c = 0
+        for t in self._env.plan.action_terms:
+            if t.func.rsplit(":", 1)[-1].rsplit(".", 1)[-1] == "EMAJointPositionToLimitsAction":
+                from .robots import resolve_matching_names
+
+                jids = resolve_matching_names(t.params["joint_names"], self._env.plan.robot.joint_names, bool(t.params.get("preserve_order")))[0]
+                rows = torch.arange(self._env.num_envs, device=self._env.device)[ids]
+                self._env._processed_action[rows.unsqueeze(1), torch.arange(c, c + t.dim, device=self._env.device)] = \
+                    self._env.feed["joint_pos"][rows][:, jids]
+            c += t.dim
         return {}
 
 

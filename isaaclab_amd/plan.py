@@ -37,6 +37,7 @@ R = dict(OP=0, IDS_OFF=1, NIDS=2, IDS2_OFF=3, NIDS2=4, WEIGHT=5, P0=6, P1=7, P2=
 F_NOISE_ADD, F_NOISE_SCALE, F_NOISE_ABS, F_CLIP, F_SCALE, F_QUAT_UNIQUE, F_MODIFIERS, F_SCAN_TWIN = 1, 2, 4, 8, 16, 32, 64, 128
 F_NOISE_GAUSS = 1024
 F_ACT_TO_LIMITS = 8
+F_ACT_EMA = 16
 M_OPS = dict(SCALE=1, BIAS=2, CLIP=3, INTEGRATOR=4, DIGITAL_FILTER=5)
 F_ACT_DEFAULT_POS_OFFSET, F_ACT_DEFAULT_VEL_OFFSET, F_ACT_CLIP = 1, 2, 4
 
@@ -326,15 +327,26 @@ class PlanCompiler:
             cls = func_name(tcfg["class_type"])
             _, cname = _short(cls)
             if cname not in ("JointPositionAction", "JointVelocityAction", "JointEffortAction", "RelativeJointPositionAction",
-                             "JointPositionToLimitsAction"):
+                             "JointPositionToLimitsAction", "EMAJointPositionToLimitsAction"):
                 raise NotImplementedError(f"action term '{name}': class {cls} is not on the fused path")
             ids, jn = resolve_matching_names(tcfg["joint_names"], self.joint_names, bool(tcfg.get("preserve_order")))
             dim = len(ids)
             rec = dict(op=A_JOINT_AFFINE, ids_off=blob.ints(ids), nids=dim, out=A, dim=dim)
             flags = 0
             scale, offset = tcfg.get("scale", 1.0), tcfg.get("offset", 0.0)
-            if cname == "JointPositionToLimitsAction" or (cname == "RelativeJointPositionAction" and tcfg.get("use_zero_offset", True)):
+            if cname.endswith("JointPositionToLimitsAction") or (cname == "RelativeJointPositionAction" and tcfg.get("use_zero_offset", True)):
                 offset = 0.0  # joint_actions_to_limits.py:111 (no offset at all), joint_actions.py:180-182
+            if cname == "EMAJointPositionToLimitsAction":  # the offset slots carry the moving-average weight (:174-193)
+                offset = tcfg.get("alpha", 1.0)
+                if isinstance(offset, dict):
+                    for jname_, v_ in zip(*resolve_matching_names_values(offset, jn)[1:]):
+                        if not 0.0 <= v_ <= 1.0:
+                            raise ValueError(f"Moving average weight must be in the range [0, 1]. Got {v_} for joint {jname_}.")
+                elif isinstance(offset, float):
+                    if not 0.0 <= offset <= 1.0:
+                        raise ValueError(f"Moving average weight must be in the range [0, 1]. Got {offset}.")
+                else:
+                    raise ValueError(f"Unsupported moving average weight type: {type(offset)}. Supported types are float and dict.")
             if not isinstance(scale, (int, float, dict)):
                 raise ValueError(f"Unsupported scale type: {type(scale)}. Supported types are float and dict.")
             if not isinstance(offset, (int, float, dict)):
@@ -348,7 +360,7 @@ class PlanCompiler:
             else:
                 rec["p0"] = float(scale)
             if isinstance(offset, dict):
-                tab = [0.0] * dim
+                tab = [1.0 if cname == "EMAJointPositionToLimitsAction" else 0.0] * dim
                 i_, _, v_ = resolve_matching_names_values(offset, jn)
                 for i, v in zip(i_, v_):
                     tab[i] = float(v)
@@ -359,8 +371,10 @@ class PlanCompiler:
                 flags |= F_ACT_DEFAULT_POS_OFFSET
             if cname == "JointVelocityAction" and tcfg.get("use_default_offset", True):
                 flags |= F_ACT_DEFAULT_VEL_OFFSET
-            if cname == "JointPositionToLimitsAction" and tcfg.get("rescale_to_limits", True):
+            if cname.endswith("JointPositionToLimitsAction") and tcfg.get("rescale_to_limits", True):
                 flags |= F_ACT_TO_LIMITS
+            if cname == "EMAJointPositionToLimitsAction":
+                flags |= F_ACT_EMA
             if tcfg.get("clip") is not None:
                 if not isinstance(tcfg["clip"], dict):
                     raise ValueError(f"Unsupported clip type: {type(tcfg['clip'])}. Supported types are dict.")

@@ -434,6 +434,7 @@ def run_task(task: str, env_cfg, agent_cfg, robot: RobotSpec, N: int, steps: int
     # ---- reset() : ManagerBasedEnv.reset (manager_based_env.py:264-315) -> obs only
     for n in in_names:
         put(f"reset/in/{n}", feed[n])
+    env.action_manager.reset(torch.arange(N))  # ManagerBasedEnv.reset -> _reset_idx(all) -> ActionManager.reset (an EMA term starts from the joint positions)
     if scanner is not None:  # ManagerBasedEnv.reset -> _reset_idx -> scene.reset(env_ids) -> RayCaster.reset (drift drawn here)
         scanner.reset(torch.arange(N))
         put("reset/scan_drift", scanner.drift)
@@ -735,8 +736,11 @@ def main():
         act_cfg.actions.haa_rel = mdp.RelativeJointPositionActionCfg(asset_name="robot", joint_names=[".*HAA"], scale=0.3, offset=0.7)
         act_cfg.actions.hfe_lim = mdp.JointPositionToLimitsActionCfg(asset_name="robot", joint_names=[".*HFE"], scale={".*F_HFE": 0.8, ".*H_HFE": 0.4},
                                                                       clip={"LF_HFE": (-0.5, 0.25)})
-        act_cfg.actions.kfe_vel = mdp.JointVelocityActionCfg(asset_name="robot", joint_names=[".*KFE"], scale=2.0, use_default_offset=False,
-                                                             offset={"L.*": 0.1, "R.*": -0.1}, clip={"R.*KFE": (-1.5, 1.5)})
+        act_cfg.actions.kfe_vel = mdp.JointVelocityActionCfg(asset_name="robot", joint_names=["L.*KFE"], scale=2.0, use_default_offset=False,
+                                                             offset={"LF.*": 0.1, "LH.*": -0.1}, clip={"LH_KFE": (-1.5, 1.5)})
+        # (over ALL joints: the reference's EMA reset indexes with env_ids[:, None] and raises for a joint subset, joint_actions_to_limits.py:206)
+        act_cfg.actions.all_ema = mdp.EMAJointPositionToLimitsActionCfg(asset_name="robot", joint_names=[".*"], scale=0.9,
+                                                                        alpha={".*HAA": 0.3, ".*HFE": 0.75, ".*KFE": 1.0})
         run_task("Isaac-Velocity-Flat-Anymal-C-v0-actions", act_cfg, AnymalCFlatPPORunnerCfg(), ANYMAL_C, N=64, steps=3, seed=110)
     if want("Isaac-Velocity-Flat-Anymal-C-v0-mod"):
         # observation modifiers (ObservationTermCfg.modifiers; utils/modifiers/modifier.py): stateless chain, IIR/FIR filter,

@@ -24,6 +24,7 @@ def test_oracle_matches_reference(task):
     has_scan = g.mesh() is not None
     if has_scan:
         env.ray_hits_w = g.t("reset/ray_hits_w")
+    env.reset_action_terms()  # ManagerBasedEnv.reset -> _reset_idx(all) -> ActionManager.reset
     obs = env.compute_observations(g.t("reset/noise_u"))
     assert_close(obs, g.t("reset/obs"), 1e-6, "reset obs")
     env.episode_length_buf[:] = g.t("reset/episode_length_buf")
