@@ -414,12 +414,6 @@ def main():
                 _, env_big, _ = build_env(args.task, big_n, device, 7, 1, tuple(args.terrain_tiles), mesh=env.terrain)
                 env_big.reset()
                 kb = time_obs_kernel(env_big, launches=50)
-                if os.environ.get("IMX_BENCH_DEBUG"):
-                    sys.stderr.write("large-n first %.1f us, again %.1f us\n" % (kb * 1e6, time_obs_kernel(env_big, launches=50) * 1e6))
-                    torch.cuda.synchronize()
-                    import gc; gc.collect(); torch.cuda.empty_cache()
-                    sys.stderr.write("large-n after empty_cache %.1f us\n" % (time_obs_kernel(env_big, launches=50) * 1e6))
-                    sys.stderr.write("mem allocated %.1f GB reserved %.1f GB\n" % (torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
                 out["roofline_large_n"] = {"num_envs": big_n, "kernel": out["roofline"]["kernel"], "avg_launch_us": kb * 1e6,
                                            "achieved": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9,
                                            "frac": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9 / HBM_PEAK_GBS,

@@ -215,19 +215,22 @@ IMX_DEV float4 scanner_step(const PlanView& P, const imx_buffers_t& Bf, int64_t 
     if (!repeat) {
         for (int k = 0; k < P.scan_substeps; ++k) ts = ts + P.scan_dt;  // SensorBase.update(dt): once per physics step, fp32 like the tensor
         outdated = outdated || (ts - last + 1.0e-6f >= P.scan_period);
-        if (was_reset) {  // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift
-            ts = 0.0f; last = 0.0f; outdated = true;
-            if (Bf.scan_drift_feed) {
-                drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
-            } else {
-                const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
-                drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
-                dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
-                drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
-            }
-        }
     } else {
         outdated = last == ts;  // the first call of this step refreshed the sensor: cast again (same pose, same hits)
+    }
+    // SensorBase.reset + RayCaster.reset: timers to zero, outdated, new drift.  Also on a repeated call of the same step: env.reset()
+    // / env.reset(env_ids) after a step go through k_frame with the stamp k_term_rew left (manager_based_env.py:264-315 -> scene.reset);
+    // for an env the step itself reset this repeats the same assignment (same seed, step, env -> same drift).
+    if (was_reset) {
+        ts = 0.0f; last = 0.0f; outdated = true;
+        if (Bf.scan_drift_feed) {
+            drx = Bf.scan_drift_feed[e * 3]; dry = Bf.scan_drift_feed[e * 3 + 1]; drz = Bf.scan_drift_feed[e * 3 + 2];
+        } else {
+            const float w = P.drift_hi - P.drift_lo;  // Tensor.uniform_(lo, hi)
+            drx = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3) * w + P.drift_lo;
+            dry = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 1) * w + P.drift_lo;
+            drz = uniform01(seed ^ 0xD21F7ull, step, (uint64_t)e * 3 + 2) * w + P.drift_lo;
+        }
     }
     float flags = 0.0f;
     if (outdated) {  // _update_buffers_impl: pos_w = root pos + drift; _update_outdated_buffers: last update <- timestamp
@@ -1189,7 +1192,8 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
         }
     }
     for (int k = 0; k < plan->nrew; ++k) {
-        if (w[plan->rew_off + k * IMX_REC_WORDS + IMX_R_WEIGHT] == 0) continue;  // +0.0f: skipped at run time, reads nothing
+        // (zero-weight terms too: imx_plan_update / set_term_cfg can wake one in place while a captured graph keeps replaying this
+        //  launch with the state pointers it was captured with -- a NULL tensor would then be a device fault, not an error return)
         switch (w[plan->rew_off + k * IMX_REC_WORDS + IMX_R_OP]) {
             case IMX_W_BASE_HEIGHT_L2: if (need(st->root_pos_w, "root_pos_w")) return 1; break;
             case IMX_W_JOINT_TORQUES_L2: if (need(st->applied_torque, "applied_torque")) return 1; break;
@@ -1271,7 +1275,6 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     // fit in three waves the remaining (cheap) columns ride as a second trip of the first lanes instead of a fourth wave
     int bs = plan->DC <= 64 ? 64 : (plan->DC <= 128 ? 128 : (plan->DC <= 192 ? 192 : 256));
     if (plan->DC > 192 && plan->n_ray_cols > 0 && plan->n_ray_cols <= 192 && plan->DC <= 2 * 192) bs = 192;
-    if (getenv("IMX_OBS_BS")) bs = atoi(getenv("IMX_OBS_BS"));
     const PlanView pv = imx_plan_view(plan);
     IMX_REQUIRE(bf->scratch, "imx_observations: scratch buffer missing");
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));

@@ -100,6 +100,31 @@ class TerrainMesh:
             pass
 
 
+# ---------------------------------------------------------------------------------------------------- term contract
+class ManagerTermBase:
+    """The class form of a manager term (managers/manager_base.py:28-115): built once as ``cls(cfg=term_cfg, env=env)``, called every step
+    as ``term(env, **params)``, ``reset(env_ids)`` for the envs of a reset.  Stand-in for users without ``isaaclab`` installed; a subclass of
+    the reference's own ``isaaclab.managers.ManagerTermBase`` is handled the same way (any class given as ``func`` is)."""
+
+    def __init__(self, cfg, env):
+        self.cfg = cfg
+        self._env = env
+
+    @property
+    def num_envs(self) -> int:
+        return self._env.num_envs
+
+    @property
+    def device(self):
+        return self._env.device
+
+    def reset(self, env_ids=None) -> None:
+        pass
+
+    def __call__(self, *args):
+        raise NotImplementedError("The method '__call__' should be implemented by the subclass.")
+
+
 # ---------------------------------------------------------------------------------------------------- manager views
 class TermCfgView:
     """What ``get_term_cfg`` hands out (RewardTermCfg / TerminationTermCfg surface: ``func``, ``params``, ``weight`` /
@@ -456,6 +481,41 @@ class _Scene:
         return self._e[k]
 
 
+def _seed_process(seed: int = -1) -> int:
+    """``ManagerBasedEnv.seed`` (envs/manager_based_env.py:425-443, a ``@staticmethod``): torch / numpy / random seeding."""
+    import random
+
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    random.seed(seed)
+    return seed
+
+
+def _seed_env(env, seed: int = -1) -> int:
+    """The same on an instance -- and the seeds of the in-kernel generators (observation noise, sensor drift; command, reset-event and
+    interval-event draws when the env owns those producers), so that "same seed, same rollout"
+    (isaaclab_tasks/test/test_environment_determinism.py:57-66) holds for seeds given after construction too."""
+    _seed_process(seed)
+    if getattr(env, "_counters", None) is not None:
+        env.noise_seed = int(seed) & 0xFFFFFFFFFFFF  # streams are keyed by (seed, step counter, env, column)
+        for name in ("command_term", "reset_events", "event_manager"):
+            prod = getattr(env, name, None)
+            if prod is not None and hasattr(prod, "seed"):
+                prod.seed = env.noise_seed
+    return seed
+
+
+class _SeedMethod:
+    """Descriptor: ``ManagerBasedRLEnv.seed(42)`` works on the class as in the reference, ``env.seed(42)`` also reaches the kernels."""
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return _seed_process
+        import functools
+
+        return functools.partial(_seed_env, obj)
+
+
 # ---------------------------------------------------------------------------------------------------- the env
 class ManagerBasedRLEnv:
     """Drop-in for ``isaaclab.envs.ManagerBasedRLEnv`` on the fused HIP path.
@@ -636,6 +696,7 @@ class ManagerBasedRLEnv:
             self.sim_writes = {"root_pose": torch.zeros(N, 7, device=self.device), "root_vel": torch.zeros(N, 6, device=self.device),
                                "joint_pos": torch.zeros(N, J, device=self.device), "joint_vel": torch.zeros(N, J, device=self.device)}
         self.scene = _Scene(self)
+        self._class_terms: list = []  # instances of class-based Python-evaluated terms, in construction order
         self._ext_funcs = {
             "rew": [(t, self._resolve_ext(t)) for t in plan.reward_terms if t.external is not None],
             "term": [(t, self._resolve_ext(t)) for t in plan.termination_terms if t.external is not None],
@@ -681,19 +742,7 @@ class ManagerBasedRLEnv:
         """Ascending ids of the envs reset in the last step (host sync: reads the device-side count)."""
         return self._reset_env_ids[: int(self._counters[0].item())]
 
-    def seed(self, seed: int = -1) -> int:
-        """ManagerBasedEnv.seed (envs/manager_based_env.py: torch / numpy seeding) -- and the seeds of the in-kernel generators
-        (observation noise, sensor drift; command and reset-event draws when the env owns those producers), so that "same seed, same
-        rollout" (isaaclab_tasks/test/test_environment_determinism.py:57-66) holds for seeds given after construction too."""
-        torch.manual_seed(seed)
-        np.random.seed(seed % (2 ** 32))
-        if getattr(self, "_counters", None) is not None:
-            self.noise_seed = int(seed) & 0xFFFFFFFFFFFF  # streams are keyed by (seed, step counter, env, column)
-            if getattr(self, "command_term", None) is not None:
-                self.command_term.seed = self.noise_seed
-            if getattr(self, "reset_events", None) is not None and hasattr(self.reset_events, "seed"):
-                self.reset_events.seed = self.noise_seed
-        return seed
+    seed = _SeedMethod()  # callable on the class (the reference's @staticmethod) and on an instance (also reseeds the kernels)
 
     def _configure_gym_env_spaces(self):
         """manager_based_rl_env.py:319-345: single_* spaces per env (Dict of Box per observation group, Box for the action) and their
@@ -769,11 +818,27 @@ class ManagerBasedRLEnv:
         managers/manager_base.py:278-395: SceneEntityCfg parameters are resolved against the scene once)."""
         from .plan import PlanCompiler
 
+        import inspect
+
         f = term.external
         fn = _string_to_callable(f) if isinstance(f, str) else f
         comp = PlanCompiler(self._cfg_dict, self._robot)
         term.call_params = {k: (_SceneEntityView(v, comp) if _looks_like_scene_entity(v) else v) for k, v in term.params.items()}
         term.py_mod_funcs = [(_string_to_callable(m) if isinstance(m, str) else m, mp) for m, mp in term.py_modifiers]
+        if inspect.isclass(fn):
+            # a class term (manager_base.py:324-327,393-395): instantiated ONCE with (cfg, env); the instance is what gets called every
+            # step, and its reset(env_ids) runs for the envs of every reset (reward_manager.py:123-124, observation_manager.py:224)
+            inst = getattr(term, "class_instance", None)
+            if inst is None:
+                entry = {"func": fn, "params": term.call_params}
+                if hasattr(term, "weight"):
+                    entry["weight"] = term.weight
+                inst = fn(cfg=TermCfgView(entry), env=self)
+                if not callable(inst):
+                    raise TypeError(f"class term '{term.name}': {fn.__name__} instances are not callable (ManagerTermBase.__call__)")
+                term.class_instance = inst
+                self._class_terms.append(inst)
+            return inst
         return fn
 
     def _state(self) -> ImxState:
@@ -861,6 +926,9 @@ class ManagerBasedRLEnv:
         self.action_manager.reset(ids)
         self._episode_length_buf[ids] = 0
         self.extras["log"] = log
+        for inst in self._class_terms:  # every manager's reset(env_ids) reaches its class terms (manager_based_env.py:264-315 -> _reset_idx)
+            if hasattr(inst, "reset"):
+                inst.reset(env_ids=None if env_ids is None else env_ids)
         f = self.feed
         if self.contact_sensor is not None:
             self.contact_sensor.reset(None if env_ids is None else env_ids)
@@ -899,6 +967,15 @@ class ManagerBasedRLEnv:
         check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
                                                  ctypes.byref(self._bufs), 1 if self.defer_step_tail else 0, _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
+        if self._class_terms:
+            # _reset_idx reaches the class terms between the reward and the observation pass (manager_based_rl_env.py:215-218 ->
+            # RewardManager.reset / ObservationManager.reset).  This route is Python-evaluated anyway: the ids are read like the
+            # reference reads them (reset_buf.nonzero: one host round trip)
+            rids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+            if len(rids) > 0:
+                for inst in self._class_terms:
+                    if hasattr(inst, "reset"):
+                        inst.reset(env_ids=rids)
         if self.reset_events is not None:  # EventManager.apply(mode="reset", env_ids=reset_env_ids) as one masked launch
             f, w = self.feed, self.sim_writes
             self.reset_events.reset(self.reset_buf, self.default_root_state, f["env_origins"], w["root_pose"], w["root_vel"],

@@ -26,6 +26,10 @@ class ActorCritic(nn.Module):
 
     def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256),
                  critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0, noise_std_type="scalar", **kwargs):
+        if kwargs:  # upstream prints and ignores them; a recurrent / cascade cfg silently trained as a plain MLP is worse than an error
+            raise NotImplementedError(
+                "ActorCritic got arguments it does not implement: " + ", ".join(sorted(kwargs)) + " -- recurrent (rnn_*), cascade "
+                "(lidar_input_dim, mlp*_...) and other policy variants are outside the hot-path scope (SURVEY.md section 8)")
         super().__init__()
         self.actor = _mlp(num_actor_obs, list(actor_hidden_dims), num_actions, activation)
         self.critic = _mlp(num_critic_obs, list(critic_hidden_dims), 1, activation)

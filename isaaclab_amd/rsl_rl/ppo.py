@@ -350,7 +350,10 @@ class PPO:
     def __init__(self, policy, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
                  use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu",
-                 normalize_advantage_per_mini_batch=False, rnd_cfg=None, symmetry_cfg=None, multi_gpu_cfg=None, **kwargs):
+                 normalize_advantage_per_mini_batch=False, rnd_cfg=None, symmetry_cfg=None, multi_gpu_cfg=None, two_streams=True,
+                 **kwargs):
+        if kwargs:  # e.g. the PPOCA / distillation cfg fields of isaaclab_rl/rsl_rl/rl_cfg.py:166-176
+            raise NotImplementedError("PPO got arguments it does not implement: " + ", ".join(sorted(kwargs)))
         if rnd_cfg is not None or symmetry_cfg is not None:
             raise NotImplementedError("RND / symmetry augmentation are outside the hot-path scope (SURVEY.md section 8)")
         self.device = torch.device(device)
@@ -396,7 +399,7 @@ class PPO:
         self._critic_layers = _mlp_layers(self.policy.critic)
         self._ws: dict = {}
         self._side = None
-        self.two_streams = kwargs.get("two_streams", True)
+        self.two_streams = bool(two_streams)
         if self.device.type == "cuda":
             # HIP binds a stream to one of a few hardware queues at its FIRST use, round-robin: touch the update's streams
             # now, in a fixed order, so that main / side / aux never end up sharing a queue depending on what ran before
@@ -659,9 +662,6 @@ class PPO:
         Rough-Anymal-C 17.7 -> 17.3 ms) but the runtime's own placement of the three branches can lose to the hand-ordered eager
         issue (Rough-G1: 21.7 -> 24.4 ms).  So it is measured, once: call 1 eager (allocations, GEMM tuning), call 2 eager between
         two events, call 3 capture + replay, call 4 replay between two events, and from call 5 on the faster of the two."""
-        if (self.update_graph == "segments" and self.device.type == "cuda" and self.is_multi_gpu
-                and not self.normalize_advantage_per_mini_batch):
-            return self._update_segments()  # opt-in (IMX_UPDATE_GRAPH=segments): measured SLOWER than the eager update, see _update_segments
         if not (self.update_graph and self.device.type == "cuda" and not self.is_multi_gpu) or self._update_t == "eager":
             return self._update_eager()
         self._update_calls += 1
@@ -701,56 +701,6 @@ class PPO:
             if c == 4:
                 self._update_ev[3].record()
         self.storage.clear()
-        return self._stats
-
-    _seg = None
-    _seg_calls = 0
-
-    def _update_segments(self):
-        """Data-parallel update as hipGraph SEGMENTS: per minibatch one replay of [gather + forward + loss + backward] (one graph per
-        minibatch index: the index slice is baked in, the permutation buffer it points into is redrawn eagerly per update), the
-        bucket all-reduce issued eagerly between the graphs (RCCL is never captured), one replay of [grad norm + adaptive-KL rule +
-        Adam] (the same graph for every minibatch).  Same kernels, same order, same arithmetic as ``_update_eager`` -- the replays only
-        remove the host's ~1200 launches per update from the critical path.  First call eager (allocations, GEMM tuning), second call
-        captures.  MEASURED (single-rank RCCL group, bench.py with IMX_FORCE_DIST=1): 30.6 ms per update against 18.0 ms eager -- 40
-        launches of three-stream graphs per update cost more in launch latency than the host's 1200 kernel launches they replace, and the
-        rollout graph next to them slowed down too (3.1 -> 6.6 ms).  So this is NOT the default for N > 1 (the eager update is); it stays
-        as an option (``update_graph = "segments"`` / ``IMX_UPDATE_GRAPH=segments``) with its bit-exactness tests."""
-        self._seg_calls += 1
-        if self._seg_calls == 1:
-            return self._update_eager()
-        st = self.storage
-        nmb = self.num_mini_batches
-        L = lib()
-        b = self.bucket
-        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
-        with torch.inference_mode():
-            if self._seg is None:
-                torch.cuda.synchronize(self.device)
-                st._minibatch_setup(nmb)  # buffers only: the permutation is drawn once per update, below, like the eager path does
-                graphs = []
-                for i in range(nmb):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self.minibatch_step(*st.gather_minibatch(i, nmb))
-                    graphs.append(g)
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
-                    check(L.imx_adam_update_norm(b.numel, b.flat.data_ptr(), b.grad.data_ptr(), b.exp_avg.data_ptr(), b.exp_avg_sq.data_ptr(),
-                                                 self._adam.data_ptr(), self._kl.data_ptr() if adaptive else None,
-                                                 float(self.desired_kl or 0.0), float(self.max_grad_norm or 0.0), self.betas[0],
-                                                 self.betas[1], self.eps, self._norm_scratch.data_ptr(), self._norm_scratch.numel(),
-                                                 _lib.current_stream(self.device)))
-                self._seg = (graphs, ga)
-            graphs, ga = self._seg
-            self._stats.zero_()
-            st.draw_permutation(nmb)
-            for _ in range(self.num_learning_epochs):
-                for i in range(nmb):
-                    graphs[i].replay()
-                    self.reduce_parameters()
-                    ga.replay()
-        st.clear()
         return self._stats
 
     def _update_eager(self):

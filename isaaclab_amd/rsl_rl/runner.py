@@ -57,6 +57,15 @@ class OnPolicyRunner:
         self.policy_cfg = dict(train_cfg["policy"])
         self.device = torch.device(device)
         self.env = env
+        # isaaclab_rl/rsl_rl/rl_cfg.py:22,62-99,107-176: upstream's runner eval()s these names.  Only the feed-forward ActorCritic +
+        # PPO pair is built here; anything else (ActorCriticRecurrent, the fork's ActorCriticCascade / PPOCA, Distillation) must not
+        # silently train a plain PPO
+        pol_cls = self.policy_cfg.pop("class_name", "ActorCritic")
+        alg_cls = self.alg_cfg.get("class_name", "PPO")
+        if pol_cls != "ActorCritic":
+            raise NotImplementedError(f"policy class '{pol_cls}' is not implemented (only 'ActorCritic'); SURVEY.md section 8 scope")
+        if alg_cls != "PPO":
+            raise NotImplementedError(f"algorithm class '{alg_cls}' is not implemented (only 'PPO'); SURVEY.md section 8 scope")
         self._configure_multi_gpu()
         if self.device.type == "cuda":
             enable_recorded_gemm_tuning()
@@ -64,7 +73,6 @@ class OnPolicyRunner:
         num_obs = obs.shape[1]
         num_privileged_obs = extras["observations"]["critic"].shape[1] if "critic" in extras["observations"] else num_obs
         self.privileged_obs_type = "critic" if "critic" in extras["observations"] else None
-        self.policy_cfg.pop("class_name", None)
         policy = ActorCritic(num_obs, num_privileged_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
         self.alg_cfg.pop("class_name", None)
         self.alg = PPO(policy, device=self.device, multi_gpu_cfg=self.multi_gpu_cfg, **self.alg_cfg)
@@ -92,8 +100,6 @@ class OnPolicyRunner:
         self.tot_time = 0.0
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self.alg.update_graph = self.use_graph and os.getenv("IMX_UPDATE_GRAPH", "1") != "0"
-        if self.alg.update_graph and os.getenv("IMX_UPDATE_GRAPH") == "segments":
-            self.alg.update_graph = "segments"  # N > 1 only: per-minibatch graph segments (measured slower than eager; opt-in)
         self._graph = None
         N = self.env.num_envs
         self._cur_reward_sum = torch.zeros(N, device=self.device)

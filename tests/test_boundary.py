@@ -151,3 +151,35 @@ def test_env_fails_loudly_without_a_gpu():
 
     with pytest.raises(_lib.ImxError):
         ManagerBasedRLEnv("Isaac-Cartpole-v0", num_envs=8)
+
+
+def test_runner_refuses_policy_and_algorithm_classes_it_does_not_build():
+    """isaaclab_rl/rsl_rl/rl_cfg.py:22,86-99,166: ActorCriticRecurrent / ActorCriticCascade / PPOCA / Distillation cfgs must not train
+    a plain feed-forward PPO silently."""
+    from isaaclab_amd.env import load_task_cfg
+    from isaaclab_amd.rsl_rl import OnPolicyRunner
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    agent = load_task_cfg("Isaac-Cartpole-v0")["agent"]
+    for section, name in (("policy", "ActorCriticRecurrent"), ("policy", "ActorCriticCascade"), ("algorithm", "PPOCA"), ("algorithm", "Distillation")):
+        cfg = {**agent, section: {**agent[section], "class_name": name}}
+        with pytest.raises(NotImplementedError, match=name):
+            OnPolicyRunner(env=None, train_cfg=cfg, device="cpu")  # refused before the env is touched
+    with pytest.raises(NotImplementedError, match="rnn_type"):
+        ActorCritic(4, 4, 1, rnn_type="lstm", rnn_hidden_dim=64, rnn_num_layers=1)
+    pol = ActorCritic(4, 4, 1, actor_hidden_dims=[8], critic_hidden_dims=[8])
+    with pytest.raises(NotImplementedError, match="teacher_coef"):
+        PPO(pol, teacher_coef=1.0)
+
+
+def test_seed_is_callable_on_the_class_like_the_reference_staticmethod():
+    """envs/manager_based_env.py:425-443: ``ManagerBasedEnv.seed`` is a @staticmethod."""
+    import torch
+
+    from isaaclab_amd.env import ManagerBasedRLEnv
+
+    assert ManagerBasedRLEnv.seed(42) == 42
+    a = torch.rand(3)
+    assert ManagerBasedRLEnv.seed(42) == 42
+    assert torch.equal(a, torch.rand(3))

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def _worker(rank, world, port, out, segments=False):
+def _worker(rank, world, port, out):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -27,11 +27,11 @@ def _worker(rank, world, port, out, segments=False):
     alg = PPO(pol, device="cuda:0", multi_gpu_cfg={"global_rank": rank, "local_rank": rank, "world_size": world}, num_learning_epochs=2,
               num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005, max_grad_norm=1.0,
               clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
-    alg.update_graph = "segments" if segments else False  # per-minibatch hipGraph segments, the all-reduce eager between them
+    alg.update_graph = False
     alg.init_storage("rl", N, T, (D,), (0,), (A,))
     alg.broadcast_parameters()
     g = torch.Generator().manual_seed(500 + rank)  # each rank its own rollout
-    for it in range(4 if segments else 2):
+    for it in range(2):
         st = alg.storage
         st.observations.copy_(torch.randn(T, N, D, generator=g))
         with torch.no_grad():
@@ -58,8 +58,7 @@ def _worker(rank, world, port, out, segments=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("segments", [False, True])
-def test_two_ranks_on_one_gpu_keep_identical_replicas(segments):
+def test_two_ranks_on_one_gpu_keep_identical_replicas():
     import torch.multiprocessing as mp
 
     s = socket.socket()
@@ -68,7 +67,7 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas(segments):
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, segments)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

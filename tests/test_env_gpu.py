@@ -547,6 +547,49 @@ def test_kitchen_sink_matches_reference_golden():
     env.close()
 
 
+def test_env_reset_after_a_step_resets_the_stateful_scanner():
+    """reset(env_ids) after at least one step goes through k_frame with the step stamp k_term_rew left (a "repeated" call of that step):
+    the sensor of those envs must still be reset -- timers to zero, outdated, a new drift (manager_based_env.py:264-315 -> scene.reset ->
+    SensorBase.reset :182-194 + RayCaster.reset :107-114) -- and the others left alone."""
+    from _util import KITCHEN
+
+    g = Golden(KITCHEN)
+    env = make_env(g)
+    N = g.N
+    env._noise_u = g.t("reset/noise_u").cuda()
+    env._scan_drift_feed = g.t("reset/scan_drift").cuda()
+    env.reset()
+    env._scan_state[:, 0] = g.t("reset/scan_ts0").cuda()
+    env._scan_state[:, 1] = g.t("reset/scan_ts0").cuda()
+    env.episode_length_buf = g.t("reset/episode_length_buf")
+    env._noise_u.copy_(g.t("step0/noise_u"))
+    env._scan_drift_feed.copy_(g.t("step0/scan_drift"))
+    env.step(g.t("step0/action").cuda())
+    before = env._scan_state.cpu().clone()
+    ids = torch.tensor([1, 7, 30, N - 1])
+    ids = ids[before[ids, 0] > 0.0]  # envs whose sensor clock is running (not reset by the step itself)
+    assert len(ids) >= 2
+    new_drift = torch.full((N, 3), 0.0)
+    new_drift[ids] = torch.tensor([0.011, -0.007, 0.003])
+    env._scan_drift_feed.copy_(new_drift)
+    obs, _ = env.reset(env_ids=ids.cuda())
+    after = env._scan_state.cpu()
+    others = torch.ones(N, dtype=torch.bool)
+    others[ids] = False
+    assert torch.equal(after[ids, 0], torch.zeros(len(ids))) and torch.equal(after[ids, 1], torch.zeros(len(ids))), "sensor timers of the reset envs"
+    assert torch.equal(after[ids, 2:5], new_drift[ids]), "a new drift for the reset envs"
+    assert torch.equal(after[others][:, :5], before[others][:, :5]), "the other sensors keep their clock and drift"
+    # the reset envs were cast from the drifted pose: data.pos_w z = root z + drift z
+    root_z = env.feed["root_pos_w"][ids.cuda(), 2].cpu()
+    assert_close(after[ids, 5], root_z + new_drift[ids, 2], 1e-6, "sensor data.pos_w z after the reset")
+    # and a full env.reset() after steps resets every sensor
+    env._scan_drift_feed.copy_(torch.full((N, 3), 0.002))
+    env.reset()
+    after = env._scan_state.cpu()
+    assert torch.equal(after[:, 0], torch.zeros(N)) and torch.equal(after[:, 2:5], torch.full((N, 3), 0.002))
+    env.close()
+
+
 # ---- Python-evaluated ("EXTERNAL") terms: user functions the term compiler does not know (ManagerBase term contract,
 # managers/manager_base.py:278-395: func(env, **params) -> Tensor[N, ...], SceneEntityCfg parameters resolved)
 def _user_reward(env, asset_cfg, gain: float):
@@ -644,6 +687,125 @@ def test_python_evaluated_terms_step_end_to_end():
         assert_close(env.reward_manager._episode_sums["user_rew"], orc.episode_sums["user_rew"], FLOAT_TOL, "episode sum of the user reward")
         assert_close(obs["policy"], out["obs"], FLOAT_TOL, "obs")
     assert fired > 0 and float(orc.episode_sums["user_rew"].abs().sum()) > 0
+    env.close()
+
+
+class _StreakReward:
+    """A STATEFUL class reward term (managers/manager_base.py:28-115 contract): how many steps in a row the knee joints moved fast."""
+
+    instances = 0
+
+    def __init__(self, cfg, env):
+        type(self).instances += 1
+        self.cfg, self._env = cfg, env
+        self.streak = torch.zeros(env.num_envs, device=env.device)
+        self.reset_calls = []
+
+    def reset(self, env_ids=None):
+        self.reset_calls.append(None if env_ids is None else torch.as_tensor(env_ids).cpu().clone())
+        self.streak[slice(None) if env_ids is None else env_ids] = 0.0
+
+    def __call__(self, env, asset_cfg, threshold: float):
+        fast = torch.sum(torch.abs(env.scene["robot"].data.joint_vel[:, asset_cfg.joint_ids]), dim=1) > threshold
+        self.streak = torch.where(fast, self.streak + 1.0, torch.zeros_like(self.streak))
+        return self.streak.clone()
+
+
+class _EmaObs:
+    """A stateful class observation term: moving average of the projected gravity, restarted at reset."""
+
+    def __init__(self, cfg, env):
+        self.cfg, self._env = cfg, env
+        self.ema = torch.zeros(env.num_envs, 3, device=env.device)
+
+    def reset(self, env_ids=None):
+        self.ema[slice(None) if env_ids is None else env_ids] = 0.0
+
+    def __call__(self, env, alpha: float):
+        self.ema = alpha * env.scene["robot"].data.projected_gravity_b + (1.0 - alpha) * self.ema
+        return self.ema.clone()
+
+
+def test_class_based_python_evaluated_terms():
+    """Class terms on the Python-evaluated route: built once with (cfg, env), called every step, ``reset(env_ids)`` with the ids of the
+    step's resets between the reward and the observation pass (manager_base.py:324-327,393-395; reward_manager.py:123-124;
+    observation_manager.py:224) -- against the CPU oracle carrying the same two state machines."""
+    import copy
+
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from oracle.mdp_oracle import OracleEnv
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    fx = copy.deepcopy(g.fixture)
+    ent = {"name": "robot", "joint_names": [".*KFE"], "joint_ids": "slice(None, None, None)", "body_names": None, "body_ids": "slice(None, None, None)",
+           "preserve_order": False}
+    fx["env"]["rewards"]["streak"] = {"func": _StreakReward, "params": {"asset_cfg": ent, "threshold": 3.0}, "weight": 0.5}
+    fx["env"]["observations"]["policy"]["ema"] = {"func": _EmaObs, "params": {"alpha": 0.25}, "_dim": 3, "scale": 2.0}
+    _StreakReward.instances = 0
+    env = ManagerBasedRLEnv(fx, state_feed=g.feed("cuda:0"))
+    assert _StreakReward.instances == 1 and len(env._class_terms) == 2
+    rew_inst = env._class_terms[0]
+    assert isinstance(rew_inst, _StreakReward) and rew_inst.cfg.weight == 0.5 and rew_inst.cfg.params["threshold"] == 3.0
+    D = env.plan.obs_dim
+    assert D == g.meta["obs_dim"] + 3
+
+    class Orc(OracleEnv):
+        kfe = [i for i, n in enumerate(g.robot.joint_names) if n.endswith("KFE")]
+
+        def _reward(self, fn, p):
+            if fn.endswith(":_StreakReward"):
+                fast = torch.sum(torch.abs(self.state("joint_vel")[:, self.kfe]), dim=1) > p["threshold"]
+                self.streak = torch.where(fast, self.streak + 1.0, torch.zeros_like(self.streak))
+                return self.streak.clone()
+            return super()._reward(fn, p)
+
+        def _obs_term(self, fn, p):
+            if fn.endswith(":_EmaObs"):
+                self.ema = p["alpha"] * self.projected_gravity_b + (1.0 - p["alpha"]) * self.ema
+                return self.ema.clone()
+            return super()._obs_term(fn, p)
+
+    cpu_feed = g.feed("cpu")
+    fo = copy.deepcopy(fx["env"])
+    fo["rewards"]["streak"]["func"] = "user:_StreakReward"
+    fo["observations"]["policy"]["ema"]["func"] = "user:_EmaObs"
+    orc = Orc(fo, g.robot.joint_names, g.robot.body_names, g.N, cpu_feed.__getitem__, g.meta["gravity_dir"])
+    orc.streak, orc.ema = torch.zeros(g.N), torch.zeros(g.N, 3)
+
+    def orc_reset_class_terms(ids):  # _reset_idx -> RewardManager.reset / ObservationManager.reset -> term.reset(env_ids)
+        if len(ids) > 0:
+            orc.streak[ids] = 0.0
+            orc.ema[ids] = 0.0
+
+    orc.pre_obs_hook = orc_reset_class_terms
+    gen = torch.Generator().manual_seed(5)
+    u = torch.rand(g.N, D, generator=gen)
+    env._noise_u = u.cuda()
+    obs, _ = env.reset()
+    assert rew_inst.reset_calls == [None]  # env.reset(): every env
+    assert_close(obs["policy"], orc.compute_observations(u), FLOAT_TOL, "reset obs with a class term")
+    ep = g.t("reset/episode_length_buf")
+    env.episode_length_buf = ep
+    orc.episode_length_buf[:] = ep
+    n_reset_calls = 0
+    for k in range(g.steps):
+        a = g.t(f"step{k}/action")
+        u = torch.rand(g.N, D, generator=gen)
+        env._noise_u.copy_(u)
+        obs, rew, term, tout, _ = env.step(a.cuda())
+        orc.process_action(a)
+        cpu_feed.advance()
+        out = orc.post_physics_step(u)
+        assert torch.equal(env.reset_env_ids.cpu(), out["reset_env_ids"])
+        if len(out["reset_env_ids"]) > 0:
+            n_reset_calls += 1
+            assert torch.equal(rew_inst.reset_calls[-1], out["reset_env_ids"])  # the ids of THIS step's resets, ascending
+        assert len(rew_inst.reset_calls) == 1 + n_reset_calls
+        assert_close(rew, out["reward"], FLOAT_TOL, "reward")
+        assert_close(rew_inst.streak, orc.streak, 0.0, "class reward state")
+        assert_close(env.reward_manager._episode_sums["streak"], orc.episode_sums["streak"], FLOAT_TOL, "episode sum of the class reward")
+        assert_close(obs["policy"], out["obs"], FLOAT_TOL, "obs")
+    assert n_reset_calls > 0 and float(orc.streak.sum()) > 0
     env.close()
 
 

@@ -210,3 +210,49 @@ def test_policy_is_exportable_like_the_reference_exporter(tmp_path):
     loaded = torch.jit.load(path)
     x = torch.randn(5, 48)
     assert torch.equal(loaded(x), pol.actor(x)) and torch.equal(pol.act_inference(x), pol.actor(x))
+
+
+_LIVE_CFGS = {  # task id -> (module, class) of the reference cfg its gym registry entry names (isaaclab_tasks/.../__init__.py)
+    "Isaac-Cartpole-v0": ("isaaclab_tasks.manager_based.classic.cartpole.cartpole_env_cfg", "CartpoleEnvCfg"),
+    "Isaac-Velocity-Flat-Anymal-C-v0": ("isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.flat_env_cfg", "AnymalCFlatEnvCfg"),
+    "Isaac-Velocity-Rough-Anymal-C-v0": ("isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.rough_env_cfg", "AnymalCRoughEnvCfg"),
+    "Isaac-Velocity-Rough-G1-v0": ("isaaclab_tasks.manager_based.locomotion.velocity.config.g1.rough_env_cfg", "G1RoughEnvCfg"),
+}
+
+_LIVE_SCRIPT = r"""
+import importlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from oracle import ref_import
+ref_import.install()
+from isaaclab_amd.env import load_task_cfg
+from isaaclab_amd.plan import compile_plan
+from isaaclab_amd.robots import ROBOTS
+out = {{}}
+for task, (mod, cls) in {cfgs!r}.items():
+    cfg = getattr(importlib.import_module(mod), cls)()        # the LIVE reference cfg object (configclass instance)
+    fx = load_task_cfg(task)                                   # the committed cfg.to_dict() dump
+    robot = ROBOTS[fx["robot"]]
+    live = compile_plan(cfg, robot)
+    dump = compile_plan(fx["env"], robot)
+    out[task] = bool(np.array_equal(np.asarray(live.blob), np.asarray(dump.blob))) and live.obs_dim == dump.obs_dim
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_live_reference_cfg_objects_compile_to_the_same_plan():
+    """'Configs drop in unchanged' (isaaclab_tasks/utils/parse_cfg.py:20-100): the reference's own cfg OBJECTS -- instantiated from
+    /root/reference with the simulator packages stubbed, in a child process so the stubs do not leak into this one -- compile to the
+    very plan blob the committed JSON dumps give.  Skipped where the reference is absent (the GPU box)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/source/isaaclab"):
+        pytest.skip("the reference tree is not present")
+    r = subprocess.run([sys.executable, "-c", _LIVE_SCRIPT.format(root=root, cfgs=_LIVE_CFGS)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert set(res) == set(_LIVE_CFGS) and all(res.values()), res

@@ -1,8 +1,9 @@
 import os, sys
-sys.path.insert(0, "/root/repo")
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 if os.environ.get("IMX_EXP_LIB"):
     from isaaclab_amd import _lib
-    _lib.LIB_PATH = os.path.join("/root/repo", "tools", "libimx_%s.so" % os.environ["IMX_EXP_LIB"])
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "libimx_%s.so" % os.environ["IMX_EXP_LIB"])
 import torch
 from bench import build_env
 from tools.exp_obs_util import timeit
