@@ -123,19 +123,164 @@ def measured_copy_gbs(device, mib: int = 1024, reps: int = 10) -> float:
     return 2.0 * 4.0 * n * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
-def time_obs_kernel(env, launches=200):
-    """Average duration of k_obs from HIP events on the stream it is launched on (torch's current stream)."""
-    dev = env.device
-    for _ in range(10):
-        env._compute_observations()  # k_frame + the observation kernel: the frame table of this state is current from here on
-    torch.cuda.synchronize(dev)
+_blocker = {}
+
+
+def _events_us(fn, launches, device):
+    """Average device time per call of ``fn``: back-to-back launches on torch's current stream, HIP events on that stream.  The host
+    needs 5-10 us per call (ctypes, snapshot bookkeeping) -- more than the small kernels run -- so the stream is first kept busy by a
+    few milliseconds of device-to-device copies: the launches queue up behind them and then run back to back; the events sit inside
+    the queue, after the copies."""
+    if device not in _blocker:
+        _blocker[device] = (torch.empty(128 * 1024 * 1024, device=device), torch.empty(128 * 1024 * 1024, device=device))
+    src, dst = _blocker[device]
+    torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(torch.cuda.current_stream(dev))
+    st = torch.cuda.current_stream(device)
+    for _ in range(max(2, launches // 20)):  # ~0.25 ms each
+        dst.copy_(src)
+    e0.record(st)
     for _ in range(launches):
-        env._compute_observations(frame_current=True)  # k_obs alone, as in env.step()
-    e1.record(torch.cuda.current_stream(dev))
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e-3 / launches  # seconds per launch
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e3 / launches
+
+
+def time_obs_kernel(env, launches=200):
+    """Average duration of the observation kernel ALONE, launched the way the rollout launches it: every launch on the NEXT state
+    snapshot of the feed (the 4096 footprints of a snapshot touch ~28 MB of terrain cells: on one unchanged snapshot they would all
+    be cache-hot and the figure 15 % too good -- round-2 verdict).  env.step() has the step kernel leave the frame table of the
+    state it ran on; to launch the observation kernel by itself each snapshot gets its own scratch block with the frame table
+    precomputed (k_frame), and the launches cycle (state pointers, scratch pointer) together."""
+    import ctypes
+
+    dev, feed = env.device, env.feed
+    S = feed.num_snapshots
+    own = env._scratch
+    blocks = {}
+    for _ in range(S):  # one frame table per snapshot
+        feed.advance()
+        blocks[feed.index] = own if not blocks else torch.zeros_like(own)
+        env._bufs.scratch = blocks[feed.index].data_ptr()
+        env._compute_observations()  # k_frame + the observation kernel
+    for _ in range(2 * S):
+        feed.advance()
+        env._bufs.scratch = blocks[feed.index].data_ptr()
+        env._compute_observations(frame_current=True)
+
+    def one():
+        feed.advance()
+        env._bufs.scratch = blocks[feed.index].data_ptr()
+        env._compute_observations(frame_current=True)  # the observation kernel alone, as in env.step()
+
+    try:
+        us = _events_us(one, launches, dev)
+    finally:
+        env._bufs.scratch = own.data_ptr()
+    return us * 1e-6  # seconds per launch
+
+
+def term_rew_bytes_per_env(plan, task) -> float:
+    """ALGORITHMIC bytes of k_term_rew per env-step.  Headline task: SURVEY.md section 8(d)'s hand count: reads root
+    10 f + joint acc / torque 24 f + action / prev 24 f + command 3 f + contact history of the used bodies 81 f + air / contact time 8 f
+    + episode length 8 B + episodic sums 11 f; writes reward 1 f + sums 11 f + step_reward 11 f + 3 masks + episode length 8 B + 2
+    term_dones = 757 B.  Other tasks: the same count made from the plan's terms."""
+    if task == TASK:
+        return 757.0
+    import numpy as np
+
+    from isaaclab_amd import plan as pm
+
+    w = np.asarray(plan.blob)
+    A, H = plan.action_dim, plan.history
+    K, NT = int(w[pm.H["NREW"]]), int(w[pm.H["NTERM"]])
+    # floats read per id of the term's id list (state arrays touched), by op
+    T_, W_ = pm.T_OPS, pm.W_OPS
+    per_id_t = {T_["ILLEGAL_CONTACT"]: 3 * H, T_["JOINT_POS_MANUAL_LIMIT"]: 1, T_["JOINT_VEL_LIMIT"]: 2, T_["JOINT_VEL_MANUAL_LIMIT"]: 1,
+                T_["JOINT_EFFORT_LIMIT"]: 2}
+    per_id_w = {W_["JOINT_TORQUES_L2"]: 1, W_["JOINT_VEL_L1"]: 1, W_["JOINT_VEL_L2"]: 1, W_["JOINT_ACC_L2"]: 1, W_["JOINT_DEVIATION_L1"]: 2,
+                W_["JOINT_POS_LIMITS"]: 3, W_["JOINT_VEL_LIMITS"]: 2, W_["APPLIED_TORQUE_LIMITS"]: 2, W_["UNDESIRED_CONTACTS"]: 3 * H,
+                W_["CONTACT_FORCES"]: 3 * H, W_["FEET_AIR_TIME"]: 2, W_["FEET_AIR_TIME_POSITIVE_BIPED"]: 2, W_["FEET_SLIDE"]: 3 * H + 3,
+                W_["JOINT_POS_TARGET_L2"]: 1, W_["BODY_LIN_ACC_L2"]: 3}
+    f = 10 + int(w[pm.H["CMD_DIM"]])  # root quat / lin / ang velocity, command
+    for k in range(NT):
+        r = w[int(w[pm.H["TERM_OFF"]]) + k * pm.REC_WORDS:][:pm.REC_WORDS]
+        f += per_id_t.get(int(r[pm.R["OP"]]), 0) * int(r[pm.R["NIDS"]])
+    for k in range(K):
+        r = w[int(w[pm.H["REW_OFF"]]) + k * pm.REC_WORDS:][:pm.REC_WORDS]
+        if int(r[pm.R["WEIGHT"]]) == 0:  # +0.0f: skipped at run time
+            continue
+        op = int(r[pm.R["OP"]])
+        f += 2 * A if op == W_["ACTION_RATE_L2"] else (A if op == W_["ACTION_L2"] else per_id_w.get(op, 0) * int(r[pm.R["NIDS"]]))
+    reads = 4 * (f + K) + 8    # + episodic sums, episode length
+    writes = 4 * (1 + 2 * K) + 3 + 8 + NT  # reward, sums, step_reward, three masks, episode length, term_dones
+    return float(reads + writes)
+
+
+def time_step_kernels(env, task, T, launches=200):
+    """roofline_step: every hand-written kernel of the post-physics path as the rollout runs it -- back-to-back launches of ONE kernel,
+    each on the next state snapshot, HIP events on the launch stream -- with its algorithmic bytes against the
+    8 TB/s peak.  k_term_rew is launched with the rollout slot (imx_terminations_rewards_rollout), as the three-launch rollout step does."""
+    import ctypes
+
+    from isaaclab_amd import _lib
+    from isaaclab_amd._lib import ImxRolloutSlot, check
+    from isaaclab_amd.rsl_rl.storage import gae_returns
+
+    dev, N, plan = env.device, env.num_envs, env.plan
+    L, st = env._lib, _lib.current_stream(env.device)
+    A = plan.action_dim
+    act = torch.randn(N, max(A, 1), device=dev).clamp_(-3, 3)
+    val, rew_o = torch.randn(N, 1, device=dev), torch.empty(N, 1, device=dev)
+    dones_o = torch.empty(N, 1, dtype=torch.uint8, device=dev)
+    cur_r, cur_l, eps = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(3, device=dev)
+    slot = ImxRolloutSlot(value_t=val.data_ptr(), rewards_out=rew_o.data_ptr(), dones_out=dones_o.data_ptr(), cur_reward_sum=cur_r.data_ptr(),
+                          cur_ep_len=cur_l.data_ptr(), ep_stats3=eps.data_ptr(), gamma=0.99, bootstrap_time_outs=1)
+
+    def k_action():
+        env.feed.advance()
+        env._process_action(act)
+
+    def k_term_rew():
+        env.feed.advance()
+        check(L.imx_terminations_rewards_rollout(env._plan_h, N, ctypes.byref(env._state()), ctypes.byref(env._bufs), 1, ctypes.byref(slot), st))
+
+    out = {}
+
+    def entry(name, us, nbytes, **kw):
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out[name] = {"bytes_per_launch": nbytes, "avg_launch_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, **kw}
+
+    for _ in range(3):
+        env.step(act)
+    if A > 0:
+        for _ in range(8):
+            k_action()
+        entry("k_action", _events_us(k_action, launches, dev), 6.0 * A * 4 * N,
+              what="imx_action_process alone (env.step()); in the rollout its work is the epilogue of k_mlp_infer")
+    for _ in range(8):
+        k_term_rew()
+    entry("k_term_rew", _events_us(k_term_rew, launches, dev), term_rew_bytes_per_env(plan, task) * N,
+          what="terminations + rewards + reset bookkeeping + storage slot t (rewards, dones, episode statistics); the 128 B frame / sensor "
+               "row it leaves per env is not in the algorithmic figure")
+    k_s = time_obs_kernel(env, launches)
+    entry(L.imx_observations_kernel_name(env._plan_h).decode(), k_s * 1e6, obs_kernel_bytes_per_env(plan) * N,
+          what="observation assembly" + (" + fused height-scanner ray-cast" if plan.num_rays else ""))
+    # GAE: k_gae + k_adv_normalize on storage-shaped tensors (25 B per transition: r 4, V 4, done 1, ret 4, adv 4 + normalise 8)
+    rew, values = torch.randn(T, N, 1, device=dev), torch.randn(T, N, 1, device=dev)
+    dn = (torch.rand(T, N, 1, device=dev) < 0.02).to(torch.uint8)
+    last = torch.randn(N, 1, device=dev)
+    ret, adv = torch.empty_like(rew), torch.empty_like(rew)
+    scr = torch.zeros(int(L.imx_gae_scratch_bytes(T, N)), dtype=torch.uint8, device=dev)
+
+    def gae():
+        gae_returns(rew, values, dn, last, 0.99, 0.95, True, ret, adv, scr)
+
+    for _ in range(8):
+        gae()
+    entry("k_gae + k_adv_normalize", _events_us(gae, launches, dev), 25.0 * T * N, what=f"one rollout of T = {T} steps (two launches)")
+    return out
 
 
 def cpu_baseline(task, num_envs, T, budget_s=12.0):
@@ -394,27 +539,33 @@ def main():
     }
     if rank == 0:
         env_rate, env_step_s = time_env_path(env, T, iters=20)
-        k_s = time_obs_kernel(env)
-        bytes_launch = obs_kernel_bytes_per_env(env.plan) * args.num_envs
-        achieved = bytes_launch / k_s / 1e9
         out["env_step_path"] = {"value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
                                 "what": "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # PMC passes of tools/pmc_obs.py (same config), see profiles/README.md
+        steps = time_step_kernels(env, args.task, T)
+        obs_name = env._lib.imx_observations_kernel_name(env._plan_h).decode()
+        ko = steps[obs_name]
+        traffic = traffic_src = None
+        tf = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # PMC passes of tools/pmc_obs.py (same config), see profiles/README.md
         if os.path.exists(tf) and args.num_envs == 4096 and args.task == TASK:
             traffic = json.load(open(tf)).get("k_obs_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "kernel": "k_obs_lean<false> (observation assembly + fused height-scanner ray-cast)",
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "bytes_per_launch": bytes_launch, "avg_launch_us": k_s * 1e6,
+            traffic_src = ("profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_obs.py on the same "
+                           "configuration, committed; NOT observed by this run)")
+        out["roofline"] = {"bound": "hbm", "kernel": obs_name + " (" + ko["what"] + ")",
+                           "achieved": ko["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ko["frac"],
+                           "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": ko["bytes_per_launch"],
+                           "avg_launch_us": ko["avg_launch_us"],
+                           "how": f"HIP events around 200 back-to-back launches, each on the next of the feed's {args.snapshots} state snapshots "
+                                  "(as the rollout runs it)",
                            "peak_measured_copy": measured_copy_gbs(device)}  # GB/s of a 1 GiB device-to-device copy on this box
+        out["roofline_step"] = steps
         # the same kernel at 16x the batch (65 536 envs): what the layout reaches once launch latency is amortised
         if os.environ.get("IMX_BENCH_LARGE_N", "1") == "1" and not args.no_large_n and args.task == TASK:
             try:
                 big_n = 65536
                 _, env_big, _ = build_env(args.task, big_n, device, 7, 1, tuple(args.terrain_tiles), mesh=env.terrain)
                 env_big.reset()
-                kb = time_obs_kernel(env_big, launches=50)
-                out["roofline_large_n"] = {"num_envs": big_n, "kernel": out["roofline"]["kernel"], "avg_launch_us": kb * 1e6,
+                kb = time_obs_kernel(env_big, launches=48)
+                out["roofline_large_n"] = {"num_envs": big_n, "kernel": obs_name, "avg_launch_us": kb * 1e6,
                                            "achieved": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9,
                                            "frac": obs_kernel_bytes_per_env(env_big.plan) * big_n / kb / 1e9 / HBM_PEAK_GBS,
                                            "unit": "GB/s"}

@@ -227,11 +227,27 @@ typedef struct imx_buffers {
                                     second call within one step repeat the first one's decision instead of advancing the clock again */
     float* scan_hit_z;           /* (N,R) data.ray_hits_w[..., 2] kept for envs whose sensor is not outdated at the next step */
     const float* scan_drift_feed;/* optional (N,3): drift values taken at a sensor reset instead of the in-kernel draw (parity runs) */
+    float* log_accum;            /* optional (NREW_ALL + NTERM + 1): running sum over the steps of log_out -- the runner's per-iteration
+                                    mean of extras["log"] (upstream on_policy_runner.py: ep_infos.append(infos["log"]) every step; the
+                                    dict is only REFRESHED on steps that reset something, manager_based_rl_env.py:216, so a step without
+                                    resets adds the entries of the last refresh again).  Updated where log_out is (the step tail) */
 } imx_buffers_t;
+
+/* ---- slot t of an rsl_rl RolloutStorage, filled by the step kernel itself (imx_terminations_rewards_rollout) ------------------ */
+typedef struct imx_rollout_slot {
+    const float* value_t;        /* (N)   critic values of this step (storage.values[t]) -- the time-out bootstrap reads them */
+    float* rewards_out;          /* (N)   storage.rewards[t] = reward + gamma * value_t * time_out   (PPO.process_env_step) */
+    uint8_t* dones_out;          /* (N)   storage.dones[t] = terminated | time_out                   (vecenv_wrapper.py:178) */
+    float* cur_reward_sum;       /* (N)   optional, with cur_ep_len: the runner's running episode return / length ... */
+    float* cur_ep_len;           /* (N) */
+    float* ep_stats3;            /* (3)   optional: finished episodes {sum return, sum length, count} (float atomics: logging only) */
+    float gamma;
+    int32_t bootstrap_time_outs; /* 0 for a finite-horizon task (vecenv_wrapper.py:184-185: no "time_outs" key) */
+} imx_rollout_slot_t;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char* imx_version(void);
-/* sizeof of an ABI struct as this library was compiled (which: 0 imx_state_t, 1 imx_buffers_t, 2 imx_head_loss_t), 0 for an unknown index:
+/* sizeof of an ABI struct as this library was compiled (which: 0 imx_state_t, 1 imx_buffers_t, 2 imx_head_loss_t, 3 imx_rollout_slot_t, 4 imx_policy_act_t), 0 for an unknown index:
  * a binding checks its own layout against it at load time. */
 size_t imx_struct_size(int which);
 const char* imx_last_error(void);
@@ -267,6 +283,12 @@ int imx_action_process(const imx_plan_t* plan, int64_t num_envs, const float* ac
  * with enable_corruption bit 2. */
 int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state,
                              const imx_buffers_t* buf, int flags, imx_stream_t stream);
+/* The same launch also doing what imx_rollout_post does (RslRlVecEnvWrapper.step dones, PPO.process_env_step time-out bootstrap, the
+ * runner's episode statistics) for slot t of the storage: the lanes that produce reward and masks write them there too -- one launch
+ * and one pass over the masks less per rollout step.  Bit-identical to imx_terminations_rewards followed by imx_rollout_post.
+ * slot == NULL: plain imx_terminations_rewards.  (The log accumulation of imx_rollout_post is buf->log_accum.) */
+int imx_terminations_rewards_rollout(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
+                                     int flags, const imx_rollout_slot_t* slot, imx_stream_t stream);
 
 /* ObservationManager.compute (managers/observation_manager.py:238-335) fused with RayCaster._update_buffers_impl
  * (sensors/ray_caster/ray_caster.py:220-260) + raycast_mesh (utils/warp/ops.py:24-127).
@@ -282,6 +304,9 @@ int imx_terminations_rewards(const imx_plan_t* plan, int64_t num_envs, const imx
 int imx_observations(const imx_plan_t* plan, int64_t num_envs, const imx_state_t* state, const imx_buffers_t* buf,
                      const imx_mesh_t* mesh, const float* noise_u_d, uint64_t seed, int enable_corruption,
                      float* ray_hits_out_d, imx_stream_t stream);
+/* Name of the kernel imx_observations launches for this plan ("k_obs_lean<false>", "k_obs<false,true>", ...): benchmarks and
+ * profiles attribute their timings to the kernel that actually ran.  Static string. */
+const char* imx_observations_kernel_name(const imx_plan_t* plan);
 
 /* ArticulationData.root_lin_vel_b / root_ang_vel_b / projected_gravity_b
  * (assets/articulation/articulation_data.py:512-515,603-619) = quat_rotate_inverse (utils/math.py:605-625). */
@@ -513,6 +538,32 @@ int imx_mlp_dw_elu(int64_t M, int N, int K, const float* dH_d, int64_t ldg, cons
 int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
                   const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                   float* const* out_d, imx_stream_t stream);
+
+/* PPO.act (imx_policy_act) and ActionManager.process_action (imx_action_process) in the epilogue of the actor head of imx_mlp_infer:
+ * the actor's workgroups keep their action means in LDS, sample a = mu + std * N(0,1) with the draws imx_policy_act makes (same seed,
+ * step counter and element index), write the transition {obs, actions, log-prob, mu, sigma} into slot t of the RolloutStorage and -- when
+ * `plan` is given -- run the sampled action through the env's action terms (buf->prev_action <- action <- clamp(a, pre_clip),
+ * buf->processed_action: managers/action_manager.py:318-337, envs/mdp/actions/joint_actions.py:130-139).  All of it is pre-physics, so
+ * it is valid with a simulator in the loop as well.  The critic's value goes where out_d[1] points (storage.values[t]).  Three launches
+ * (k_mlp_infer, k_policy_act, k_action) become one; results are bit-identical to the three. */
+typedef struct imx_policy_act {
+    const float* std_d;            /* (A) action std (scalar noise_std_type) */
+    uint64_t seed;
+    const int32_t* step_counter_d; /* device step counter keying the draws (buf->counters + 2), or NULL */
+    float* actions_out_d;          /* (N,A) storage.actions[t] */
+    float* logp_out_d;             /* (N)   storage.actions_log_prob[t] */
+    float* mu_out_d;               /* (N,A) storage.mu[t] */
+    float* sigma_out_d;            /* (N,A) storage.sigma[t] */
+    float* obs_out_d;              /* (N,D) storage.observations[t] (dense rows) */
+    const imx_plan_t* plan;        /* optional: also process the action (with state, buf, pre_clip) */
+    const imx_state_t* state;
+    const imx_buffers_t* buf;
+    float pre_clip;                /* RslRlVecEnvWrapper clip_actions or +inf */
+} imx_policy_act_t;
+/* out_d[0] may be NULL when act != NULL (the means go to mu_out_d); act == NULL: plain imx_mlp_infer. */
+int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
+                      const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
+                      float* const* out_d, const imx_policy_act_t* act, imx_stream_t stream);
 
 /* Output layer forward, A <= 64 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K).
  * elu_in_place != 0: h_d holds the PRE-activation output of the layer below; h <- ELU(h) (aten elu, alpha = elu_alpha) is

@@ -21,7 +21,7 @@ STATE_FIELDS = (
 BUFFER_FIELDS = (
     "episode_length_buf", "action", "prev_action", "processed_action", "reward_buf", "episode_sums", "step_reward",
     "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch", "mod_state",
-    "obs_extra1", "obs_extra2", "obs_extra3", "scan_state", "scan_hit_z", "scan_drift_feed",
+    "obs_extra1", "obs_extra2", "obs_extra3", "scan_state", "scan_hit_z", "scan_drift_feed", "log_accum",
 )
 
 
@@ -38,6 +38,17 @@ class ImxHeadLoss(ctypes.Structure):  # imx_head_loss_t
                 ("clip_param", ctypes.c_float), ("value_loss_coef", ctypes.c_float), ("entropy_coef", ctypes.c_float),
                 ("grad_scale", ctypes.c_float)] + [(n, c_void_p) for n in (
                     "sigma_d", "actions_d", "old_logp_d", "advantages_d", "returns_d", "old_values_d", "dmu_d", "dsigma_d", "dvalue_d")]
+
+
+class ImxRolloutSlot(ctypes.Structure):  # imx_rollout_slot_t
+    _fields_ = [(n, c_void_p) for n in ("value_t", "rewards_out", "dones_out", "cur_reward_sum", "cur_ep_len", "ep_stats3")] + [
+        ("gamma", ctypes.c_float), ("bootstrap_time_outs", ctypes.c_int32)]
+
+
+class ImxPolicyAct(ctypes.Structure):  # imx_policy_act_t
+    _fields_ = [("std_d", c_void_p), ("seed", ctypes.c_uint64), ("step_counter_d", c_void_p), ("actions_out_d", c_void_p),
+                ("logp_out_d", c_void_p), ("mu_out_d", c_void_p), ("sigma_out_d", c_void_p), ("obs_out_d", c_void_p),
+                ("plan", c_void_p), ("state", POINTER(ImxState)), ("buf", POINTER(ImxBuffers)), ("pre_clip", ctypes.c_float)]
 
 
 class ImxError(RuntimeError):
@@ -58,6 +69,9 @@ _SIGNATURES = {
     "imx_plan_obs_dim": (c_int, [c_void_p]),
     "imx_action_process": (c_int, [c_void_p, c_int64, c_void_p, c_float, POINTER(ImxState), POINTER(ImxBuffers), c_void_p]),
     "imx_terminations_rewards": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_int, c_void_p]),
+    "imx_terminations_rewards_rollout": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_int, POINTER(ImxRolloutSlot),
+                                                 c_void_p]),
+    "imx_observations_kernel_name": (c_char_p, [c_void_p]),
     "imx_observations": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p, c_void_p, c_uint64,
                                  c_int, c_void_p, c_void_p]),
     "imx_root_frame": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
@@ -118,6 +132,8 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "imx_mlp_infer": (c_int, [c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
+    "imx_mlp_infer_act": (c_int, [c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  POINTER(ImxPolicyAct), c_void_p]),
     "imx_mlp_head_fwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "imx_mlp_head_fwd_loss": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "imx_mlp_head_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p,
@@ -148,7 +164,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((ImxState, ImxBuffers, ImxHeadLoss)):  # the binding's struct layouts against the library's
+    for which, cls in enumerate((ImxState, ImxBuffers, ImxHeadLoss, ImxRolloutSlot, ImxPolicyAct)):  # the binding's struct layouts against the library's
         if int(L.imx_struct_size(which)) != ctypes.sizeof(cls):
             raise ImxError(f"{LIB_PATH}: sizeof({cls.__name__}) is {int(L.imx_struct_size(which))} in the library, {ctypes.sizeof(cls)} in the "
                            "binding -- rebuild with `python -m isaaclab_amd.build`")

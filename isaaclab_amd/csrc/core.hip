@@ -20,13 +20,15 @@ void imx_set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
-extern "C" const char* imx_version(void) { return "libimx 0.2 (gfx950; plan v3)"; }
+extern "C" const char* imx_version(void) { return "libimx 0.3 (gfx950; plan v3)"; }
 extern "C" const char* imx_last_error(void) { return g_err.c_str(); }
 extern "C" size_t imx_struct_size(int which) {
     switch (which) {
         case 0: return sizeof(imx_state_t);
         case 1: return sizeof(imx_buffers_t);
         case 2: return sizeof(imx_head_loss_t);
+        case 3: return sizeof(imx_rollout_slot_t);
+        case 4: return sizeof(imx_policy_act_t);
         default: return 0;
     }
 }

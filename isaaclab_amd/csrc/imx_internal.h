@@ -177,6 +177,50 @@ IMX_DEV float wrap_to_pi(float a) {
     return (m == 0.0f && a > 0.0f) ? PI : m - PI;
 }
 
+#define IMX_HALF_LOG_2PI 0.91893853320467274178f
+
+// One element of ActionManager.process_action (action_manager.py:318-337): prev <- cur; cur <- clamp(a); the owning term's
+// processed = raw*scale + offset [clamp | to-limits | EMA]  (joint_actions.py:130-139, joint_actions_to_limits.py).  Shared by k_action and
+// by the actor head of k_mlp_infer (imx_mlp_infer_act), which calls it for the action it has just sampled.
+IMX_DEV void action_process_element(const PlanView& P, const imx_state_t& S, const imx_buffers_t& Bf, int64_t e, int c, float a, float pre_clip) {
+    const int64_t i = e * P.A + c;
+    if (pre_clip < __builtin_huge_valf()) a = fminf(fmaxf(a, -pre_clip), pre_clip);  // torch.clamp
+    Bf.prev_action[i] = Bf.action[i];
+    Bf.action[i] = a;
+    // find the term that owns column c (few terms; uniform loop)
+    for (int k = 0; k < P.nact; ++k) {
+        const int32_t* r = P.w + P.act_off + k * IMX_REC_WORDS;
+        const int o = r[IMX_R_OUT], d = r[IMX_R_DIM];
+        if (c < o || c >= o + d) continue;
+        const int j = c - o;
+        const int flags = r[IMX_R_FLAGS];
+        const float scale = r[IMX_R_AUX0] ? f_of(P.w[r[IMX_R_AUX0] + j]) : f_of(r[IMX_R_P0]);
+        float offset = r[IMX_R_AUX1] ? f_of(P.w[r[IMX_R_AUX1] + j]) : f_of(r[IMX_R_P1]);
+        const int jid = P.w[r[IMX_R_IDS_OFF] + j];
+        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) offset = S.default_joint_pos[e * P.J + jid];
+        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) offset = S.default_joint_vel[e * P.J + jid];
+        float v = (flags & IMX_F_ACT_EMA) ? a * scale : a * scale + offset;  // (an EMA term has no offset: the slot carries alpha)
+        if (flags & IMX_F_ACT_CLIP) {
+            const float lo = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j]), hi = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j + 1]);
+            v = fminf(fmaxf(v, lo), hi);
+        }
+        if (flags & IMX_F_ACT_TO_LIMITS) {  // clamp(-1, 1), then unscale_transform (utils/math.py:43-61): x * (upper - lower) * 0.5 + (lower + upper) * 0.5
+            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+            v = v * (lim.y - lim.x) * 0.5f + (lim.x + lim.y) * 0.5f;
+        }
+        if (flags & IMX_F_ACT_EMA) {  // joint_actions_to_limits.py:219-230
+            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
+            const float prev = (Bf.reset_buf && Bf.reset_buf[e]) ? S.joint_pos[e * P.J + jid] : Bf.processed_action[i];
+            v = offset * v + (1.0f - offset) * prev;
+            v = fminf(fmaxf(v, lim.x), lim.y);
+        }
+        Bf.processed_action[i] = v;
+    }
+}
+// host-side validation of what action_process_element dereferences (step.hip)
+int imx_check_action_inputs(const imx_plan_t* plan, const imx_state_t* st, const imx_buffers_t* bf, const char* who);
+
 IMX_DEV float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
 
 // counter-based uniform [0,1): two rounds of a 32-bit multiply-xorshift hash (Wellons' "lowbias32") over

@@ -787,6 +787,56 @@ struct InferArgs {
     int nnets;
 };
 
+// imx_mlp_infer_act: PPO.act's sampling / log-prob / storage writes (imx_policy_act) and ActionManager.process_action
+// (imx_action_process) in the epilogue of the actor head.  The actor workgroup keeps its 32 (16) action means in LDS instead of
+// storing them, then lane = (sample, action column): a = mu + std * z with the SAME counter-based draws as k_policy_act (keyed by
+// seed, step counter, env * A + column), transition -> slot t of the storage, the action through the env's action terms; one lane
+// per sample adds the log-prob terms in column order (bit-identical to k_policy_act's sequential sum).
+struct ActArgs {
+    int enabled, A, has_plan;
+    float pre_clip;
+    const float* std_a;
+    uint64_t seed;
+    const int32_t* step_d;
+    float *act_out, *logp_out, *mu_out, *sigma_out, *obs_out;
+    PlanView P;
+    imx_state_t S;
+    imx_buffers_t Bf;
+};
+
+template <int ROWS>
+__device__ __forceinline__ void act_epilogue(const ActArgs& c, const float* __restrict__ mu_s, float* __restrict__ term_s, int64_t m0, int64_t M) {
+    const int A = c.A;
+    const uint32_t step = c.step_d ? (uint32_t)c.step_d[0] : 0u;
+    for (int i = threadIdx.x; i < ROWS * A; i += blockDim.x) {
+        const int row = i / A, a = i - row * A;
+        const int64_t e = m0 + row;
+        float term = 0.0f;
+        if (e < M) {
+            const float m = mu_s[row * INF_PITCH + a], s = c.std_a[a];
+            const float u1 = 1.0f - uniform01(c.seed, step, (uint64_t)(e * A + a) * 2);        // (0,1]
+            const float u2 = uniform01(c.seed ^ 0x5851F42D4C957F2Dull, step, (uint64_t)(e * A + a) * 2 + 1);
+            const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+            const float x = m + s * z;
+            const float d = x - m;
+            term = -(d * d) / (2.0f * s * s) - logf(s) - IMX_HALF_LOG_2PI;
+            c.act_out[e * A + a] = x;
+            c.mu_out[e * A + a] = m;
+            c.sigma_out[e * A + a] = s;
+            if (c.has_plan) action_process_element(c.P, c.S, c.Bf, e, a, x, c.pre_clip);
+        }
+        term_s[row * INF_PITCH + a] = term;
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < ROWS; row += blockDim.x) {
+        const int64_t e = m0 + row;
+        if (e >= M) continue;
+        float logp = 0.0f;
+        for (int a = 0; a < A; ++a) logp += term_s[row * INF_PITCH + a];
+        c.logp_out[e] = logp;
+    }
+}
+
 // One layer for the 32 samples of the workgroup.  NBW = 32-column output blocks per wave (4, 2 or 1); a reduction GROUP is
 // GS = 4 / NBW sub-groups of 32 indices, so that every group is 64 MFMAs per wave (4096 cycles, more than an L2 round trip)
 // whatever the layer width.  Two operand sets (P, Q) ping-pong: the loads of group g+1 are issued before the MFMAs of group
@@ -889,13 +939,14 @@ __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K
     }
 }
 
-__global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
+__global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a, ActArgs act) {
     extern __shared__ float smem[];  // two activation buffers of INF_ROWS x INF_PITCH floats
     float* buf0 = smem;
     float* buf1 = smem + INF_ROWS * INF_PITCH;
     const int which = blockIdx.x / a.tiles;
     const InferNet& net = a.net[which];
     const int64_t m0 = (int64_t)(blockIdx.x - which * a.tiles) * INF_ROWS;
+    const bool act_here = act.enabled && which == 0;  // the actor's workgroups finish PPO.act + ActionManager.process_action themselves
     // input rows -> LDS (the 32 rows are one contiguous run when ldx == dim[0]); columns up to the next multiple of 32 are zeroed
     const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
     {
@@ -923,6 +974,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
                 for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
                     const int c = lane + 64 * cc;
                     if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
+                    if (act_here && c < K0 && m0 + row < a.M) act.obs_out[(m0 + row) * (int64_t)K0 + c] = v[rr][cc];  // storage.observations[t]
                 }
             }
         }
@@ -934,7 +986,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
         const int K = net.dim[l], N = net.dim[l + 1];
         const bool last = l == net.nlayers - 1;
         const int nbw = ((N + 31) / 32 + 3) / 4;  // 32-column blocks per wave
-        float* so = last ? nullptr : out;
+        float* so = (last && !act_here) ? nullptr : out;  // (the actor head of imx_mlp_infer_act keeps its means in LDS)
         if (!last) {  // zero the padding columns the next layer's 32-wide reduction groups will read
             const int Np = (N + 31) & ~31;
             for (int i = threadIdx.x; i < INF_ROWS * (Np - N); i += blockDim.x) {
@@ -948,6 +1000,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a) {
         __syncthreads();
         float* t = in; in = out; out = t;
     }
+    if (act_here) act_epilogue<INF_ROWS>(act, in, out, m0, a.M);
 }
 
 // ---- 16-sample variant (v_mfma_f32_16x16x4_f32) for small batches: twice the workgroups (and half the LDS each) when
@@ -1048,13 +1101,14 @@ __device__ __forceinline__ void infer_layer16(const float* __restrict__ sIn, int
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a) {
+__global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a, ActArgs act) {
     extern __shared__ float smem[];  // two activation buffers of INF16_ROWS x INF_PITCH floats
     float* buf0 = smem;
     float* buf1 = smem + INF16_ROWS * INF_PITCH;
     const int which = blockIdx.x / a.tiles;
     const InferNet& net = a.net[which];
     const int64_t m0 = (int64_t)(blockIdx.x - which * a.tiles) * INF16_ROWS;
+    const bool act_here = act.enabled && which == 0;
     const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
     {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1077,6 +1131,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a) {
             for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
                 const int c = lane + 64 * cc;
                 if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
+                if (act_here && c < K0 && m0 + row < a.M) act.obs_out[(m0 + row) * (int64_t)K0 + c] = v[rr][cc];
             }
         }
     }
@@ -1087,7 +1142,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a) {
         const int K = net.dim[l], N = net.dim[l + 1];
         const bool last = l == net.nlayers - 1;
         const int nbw = ((N + 15) / 16 + 3) / 4;  // 16-column blocks per wave
-        float* so = last ? nullptr : out;
+        float* so = (last && !act_here) ? nullptr : out;
         if (!last) {
             const int Np = (N + 31) & ~31;
             for (int i = threadIdx.x; i < INF16_ROWS * (Np - N); i += blockDim.x) {
@@ -1102,13 +1157,40 @@ __global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a) {
         __syncthreads();
         float* t = in; in = out; out = t;
     }
+    if (act_here) act_epilogue<INF16_ROWS>(act, in, out, m0, a.M);
 }
 
 extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
                              const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                              float* const* out_d, imx_stream_t stream) {
+    return imx_mlp_infer_act(M, X_d, ldx, nnets, nlayers, dims, weights_d, weight_pitch, biases_d, elu_alpha, out_d, nullptr, stream);
+}
+
+extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
+                                 const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
+                                 float* const* out_d, const imx_policy_act_t* pa, imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && X_d && nnets >= 1 && nnets <= 2 && nlayers && dims && weights_d && biases_d && elu_alpha && out_d,
                 "imx_mlp_infer: bad arguments");
+    ActArgs act{};
+    if (pa) {
+        IMX_REQUIRE(pa->std_d && pa->actions_out_d && pa->logp_out_d && pa->mu_out_d && pa->sigma_out_d && pa->obs_out_d,
+                    "imx_mlp_infer_act: null argument in imx_policy_act_t");
+        act.enabled = 1;
+        act.std_a = pa->std_d; act.seed = pa->seed; act.step_d = pa->step_counter_d;
+        act.act_out = pa->actions_out_d; act.logp_out = pa->logp_out_d; act.mu_out = pa->mu_out_d; act.sigma_out = pa->sigma_out_d;
+        act.obs_out = pa->obs_out_d;
+        act.pre_clip = pa->pre_clip;
+        act.A = dims[nlayers[0]];  // width of network 0's last layer = number of actions
+        if (pa->plan) {
+            IMX_REQUIRE(pa->state && pa->buf && pa->plan->dev, "imx_mlp_infer_act: plan without state / buffers / device tables");
+            IMX_REQUIRE(pa->plan->A == act.A, "imx_mlp_infer_act: the actor has %d outputs, the plan %d action columns", act.A, pa->plan->A);
+            if (imx_check_action_inputs(pa->plan, pa->state, pa->buf, "imx_mlp_infer_act")) return 1;
+            act.has_plan = 1;
+            act.P = imx_plan_view(pa->plan);
+            act.S = *pa->state;
+            act.Bf = *pa->buf;
+        }
+    }
     InferArgs a;
     a.M = M; a.X = X_d; a.ldx = ldx; a.nnets = nnets;
     a.tiles = (int)((M + INF_ROWS - 1) / INF_ROWS);
@@ -1135,7 +1217,7 @@ extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets
         }
         n.alpha = elu_alpha[k];
         n.out = out_d[k];
-        IMX_REQUIRE(n.out, "imx_mlp_infer: null output (network %d)", k);
+        IMX_REQUIRE(n.out || (pa && k == 0), "imx_mlp_infer: null output (network %d)", k);
     }
     if (g_num_cu == 0) (void)dw_plan(64, 32, 32);  // fills g_num_cu
     // 16-sample tiles double the weight traffic out of L2 (every workgroup reads every weight; measured ceiling ~6 TB/s for
@@ -1153,10 +1235,10 @@ extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets
     if (small) {
         a.tiles = (int)((M + INF16_ROWS - 1) / INF16_ROWS);
         hipLaunchKernelGGL(k_mlp_infer16, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF16_ROWS * INF_PITCH * sizeof(float),
-                           (hipStream_t)stream, a);
+                           (hipStream_t)stream, a, act);
     } else {
         hipLaunchKernelGGL(k_mlp_infer, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF_ROWS * INF_PITCH * sizeof(float),
-                           (hipStream_t)stream, a);
+                           (hipStream_t)stream, a, act);
     }
     IMX_HIP(hipGetLastError());
     return 0;

@@ -36,32 +36,61 @@ IMX_DEV Mom mom_wave(Mom m) {
     return m;
 }
 
+constexpr int GAE_BLOCK = 64;  // one wave per workgroup: 4096 envs = 64 workgroups on 64 CUs instead of 16 on 16
+constexpr int GAE_CHUNK = 8;   // steps whose loads are in flight together
+
 extern "C" size_t imx_gae_scratch_bytes(int64_t T, int64_t N) {
     (void)T;
-    const size_t nblk = (size_t)((N + 255) / 256);
+    const size_t nblk = (size_t)((N + GAE_BLOCK - 1) / GAE_BLOCK);
     return (nblk * 3 + 8) * sizeof(float);
 }
 
-// scratch: [0..3*nblk) per-block moments, then {mean, inv_std, ticket(int)} at [3*nblk ..]
-__global__ void __launch_bounds__(256)
+// The scan over t is a true recurrence, its LOADS are not: reward, value and done flag of every step are known before the kernel
+// starts.  The walk goes in chunks of GAE_CHUNK steps, the 3 x GAE_CHUNK loads of chunk c+1 issued before the arithmetic of chunk c
+// (two register sets, indices clamped so that every load is unconditional) -- the kernel is one or two memory round trips deep
+// instead of T of them (round 2: three dependent loads inside every trip of the recurrence, 13 us for T = 24).
+struct GaeChunk {
+    float r[GAE_CHUNK], v[GAE_CHUNK];
+    uint8_t d[GAE_CHUNK];
+};
+IMX_DEV void gae_load(GaeChunk& c, int64_t t_hi, int64_t N, int64_t e, const float* __restrict__ rew, const float* __restrict__ val,
+                      const uint8_t* __restrict__ dones) {
+#pragma unroll
+    for (int u = 0; u < GAE_CHUNK; ++u) {
+        const int64_t t = t_hi - u > 0 ? t_hi - u : 0;
+        c.r[u] = rew[t * N + e];
+        c.v[u] = val[t * N + e];
+        c.d[u] = dones[t * N + e];
+    }
+}
+
+// scratch: [0..3*nblk) per-workgroup moments of the raw advantages
+__global__ void __launch_bounds__(GAE_BLOCK)
 k_gae(int64_t T, int64_t N, const float* __restrict__ rew, const float* __restrict__ val,
       const uint8_t* __restrict__ dones, const float* __restrict__ last_val, float gamma, float lam,
       float* __restrict__ ret, float* __restrict__ adv, float* __restrict__ scratch) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = e < N;
+    const int64_t e0 = (int64_t)blockIdx.x * GAE_BLOCK + threadIdx.x;
+    const bool live = e0 < N;
+    const int64_t e = live ? e0 : N - 1;  // dead lanes walk a valid env, never store
     Mom m{0.0f, 0.0f, 0.0f};
-    if (live) {
-        float advantage = 0.0f;
-        float next_v = last_val[e];
-        for (int64_t t = T - 1; t >= 0; --t) {
-            const float v = val[t * N + e];
-            const float nnt = 1.0f - (dones[t * N + e] ? 1.0f : 0.0f);
-            const float delta = rew[t * N + e] + nnt * gamma * next_v - v;
+    float advantage = 0.0f;
+    float next_v = last_val[e];
+    GaeChunk ca, cb;
+    auto compute = [&](const GaeChunk& c, int64_t t_hi) {
+#pragma unroll
+        for (int u = 0; u < GAE_CHUNK; ++u) {
+            const int64_t t = t_hi - u;
+            if (t < 0) break;  // uniform
+            const float v = c.v[u];
+            const float nnt = 1.0f - (c.d[u] ? 1.0f : 0.0f);
+            const float delta = c.r[u] + nnt * gamma * next_v - v;
             advantage = delta + nnt * gamma * lam * advantage;
             const float r = advantage + v;
-            ret[t * N + e] = r;
             const float a = r - v;  // self.advantages = self.returns - self.values
-            adv[t * N + e] = a;
+            if (live) {
+                ret[t * N + e] = r;
+                adv[t * N + e] = a;
+            }
             // Welford update
             m.n += 1.0f;
             const float d = a - m.mean;
@@ -69,38 +98,106 @@ k_gae(int64_t T, int64_t N, const float* __restrict__ rew, const float* __restri
             m.m2 += d * (a - m.mean);
             next_v = v;
         }
+    };
+    int64_t t_hi = T - 1;
+    gae_load(ca, t_hi, N, e, rew, val, dones);
+    while (t_hi >= 0) {
+        gae_load(cb, t_hi - GAE_CHUNK, N, e, rew, val, dones);  // (clamped: a redundant reload of step 0 at the end)
+        compute(ca, t_hi);
+        t_hi -= GAE_CHUNK;
+        if (t_hi < 0) break;
+        gae_load(ca, t_hi - GAE_CHUNK, N, e, rew, val, dones);
+        compute(cb, t_hi);
+        t_hi -= GAE_CHUNK;
     }
-    __shared__ Mom sm[4];
+    if (!live) m = Mom{0.0f, 0.0f, 0.0f};
     m = mom_wave(m);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        Mom b = sm[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) b = mom_merge(b, sm[w]);
-        scratch[3 * blockIdx.x + 0] = b.n;
-        scratch[3 * blockIdx.x + 1] = b.mean;
-        scratch[3 * blockIdx.x + 2] = b.m2;
+        scratch[3 * blockIdx.x + 0] = m.n;
+        scratch[3 * blockIdx.x + 1] = m.mean;
+        scratch[3 * blockIdx.x + 2] = m.m2;
     }
 }
 
-// every block merges the per-block moments in the same fixed order (a few hundred entries) and normalises its slice
+// every wave merges the per-workgroup moments in the same fixed order -- lane i takes partials i, i + 64, ... in sequence, then the
+// symmetric shuffle tree of mom_wave -- and normalises its slice, four elements per lane and trip
 __global__ void __launch_bounds__(256)
 k_adv_normalize(int64_t total, int nblk, const float* __restrict__ scratch, float* __restrict__ adv) {
-    __shared__ float s_mean, s_inv;
-    if (threadIdx.x == 0) {
-        Mom b{0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < nblk; ++i) {
-            Mom c{scratch[3 * i], scratch[3 * i + 1], scratch[3 * i + 2]};
-            b = mom_merge(b, c);
-        }
-        const float var = b.n > 1.0f ? b.m2 / (b.n - 1.0f) : 0.0f;  // torch.std: unbiased
-        s_mean = b.mean;
-        s_inv = 1.0f / (sqrtf(var) + 1.0e-8f);
+    const int lane = threadIdx.x & 63;
+    Mom b{0.0f, 0.0f, 0.0f};
+    for (int i = lane; i < nblk; i += 64) {
+        Mom c{scratch[3 * i], scratch[3 * i + 1], scratch[3 * i + 2]};
+        b = mom_merge(b, c);
     }
-    __syncthreads();
-    const float mean = s_mean, inv = s_inv;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        adv[i] = (adv[i] - mean) * inv;
+    b = mom_wave(b);
+    const float var = b.n > 1.0f ? b.m2 / (b.n - 1.0f) : 0.0f;  // torch.std: unbiased
+    const float mean = b.mean, inv = 1.0f / (sqrtf(var) + 1.0e-8f);
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(adv) & 15) == 0) {
+        float4* a4 = reinterpret_cast<float4*>(adv);
+        const int64_t n4 = total >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            float4 x = a4[i];
+            x.x = (x.x - mean) * inv; x.y = (x.y - mean) * inv; x.z = (x.z - mean) * inv; x.w = (x.w - mean) * inv;
+            a4[i] = x;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < total; i += nth) adv[i] = (adv[i] - mean) * inv;
+    } else {
+        for (int64_t i = tid; i < total; i += nth) adv[i] = (adv[i] - mean) * inv;
+    }
+}
+
+// The usual rollout lengths (T <= 32): EVERY load of the scan in flight at once -- one memory round trip for the whole kernel.
+// (A single-launch form -- the lane keeps its T advantages in registers, the workgroups meet at an in-kernel grid barrier, every wave
+// merges the moments and stores normalised advantages once -- was built and measured: 16.1 us against 12.8 us for the two launches.
+// An agent-scope release / acquire pair on this eight-XCD part is an L2 write-back + invalidate, ~5 us, the same finding as for the
+// step tail in round 2.  Two launches stay.)
+constexpr int GAE_TMAX = 32;
+__global__ void __launch_bounds__(GAE_BLOCK)
+k_gae_short(int T, int64_t N, const float* __restrict__ rew, const float* __restrict__ val, const uint8_t* __restrict__ dones,
+            const float* __restrict__ last_val, float gamma, float lam, float* __restrict__ ret, float* __restrict__ adv,
+            float* __restrict__ scratch) {
+    const int64_t e0 = (int64_t)blockIdx.x * GAE_BLOCK + threadIdx.x;
+    const bool live = e0 < N;
+    const int64_t e = live ? e0 : N - 1;
+    float r[GAE_TMAX], v[GAE_TMAX];
+    uint8_t d[GAE_TMAX];
+    float next_v = last_val[e];
+#pragma unroll
+    for (int u = 0; u < GAE_TMAX; ++u) {  // (rows past T - 1 re-read the last one: every load unconditional)
+        const int64_t t = u < T ? u : T - 1;
+        r[u] = rew[t * N + e];
+        v[u] = val[t * N + e];
+        d[u] = dones[t * N + e];
+    }
+    Mom m{0.0f, 0.0f, 0.0f};
+    float advantage = 0.0f;
+#pragma unroll
+    for (int u = GAE_TMAX - 1; u >= 0; --u) {
+        if (u < T) {  // uniform
+            const float nnt = 1.0f - (d[u] ? 1.0f : 0.0f);
+            const float delta = r[u] + nnt * gamma * next_v - v[u];
+            advantage = delta + nnt * gamma * lam * advantage;
+            const float rt = advantage + v[u];
+            const float at = rt - v[u];  // self.advantages = self.returns - self.values
+            if (live) {
+                ret[(int64_t)u * N + e] = rt;
+                adv[(int64_t)u * N + e] = at;
+            }
+            m.n += 1.0f;
+            const float dd = at - m.mean;
+            m.mean += dd / m.n;
+            m.m2 += dd * (at - m.mean);
+            next_v = v[u];
+        }
+    }
+    if (!live) m = Mom{0.0f, 0.0f, 0.0f};
+    m = mom_wave(m);
+    if (threadIdx.x == 0) {
+        scratch[3 * blockIdx.x + 0] = m.n;
+        scratch[3 * blockIdx.x + 1] = m.mean;
+        scratch[3 * blockIdx.x + 2] = m.m2;
+    }
 }
 
 extern "C" int imx_gae(int64_t T, int64_t N, const float* rew, const float* val, const uint8_t* dones,
@@ -108,13 +205,17 @@ extern "C" int imx_gae(int64_t T, int64_t N, const float* rew, const float* val,
                        void* scratch, imx_stream_t stream) {
     IMX_REQUIRE(T > 0 && N > 0, "imx_gae: empty rollout (T=%lld N=%lld)", (long long)T, (long long)N);
     IMX_REQUIRE(rew && val && dones && last_val && ret && adv && scratch, "imx_gae: null argument");
-    const unsigned nblk = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_gae, dim3(nblk), dim3(256), 0, (hipStream_t)stream, T, N, rew, val, dones, last_val, gamma, lam,
-                       ret, adv, (float*)scratch);
+    const unsigned nblk = (unsigned)((N + GAE_BLOCK - 1) / GAE_BLOCK);
+    if (T <= GAE_TMAX)
+        hipLaunchKernelGGL(k_gae_short, dim3(nblk), dim3(GAE_BLOCK), 0, (hipStream_t)stream, (int)T, N, rew, val, dones, last_val, gamma, lam,
+                           ret, adv, (float*)scratch);
+    else
+        hipLaunchKernelGGL(k_gae, dim3(nblk), dim3(GAE_BLOCK), 0, (hipStream_t)stream, T, N, rew, val, dones, last_val, gamma, lam,
+                           ret, adv, (float*)scratch);
     IMX_HIP(hipGetLastError());
     if (normalize) {
         const int64_t total = T * N;
-        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        const unsigned grid = (unsigned)std::min<int64_t>((total / 4 + 255) / 256 + 1, 1024);
         hipLaunchKernelGGL(k_adv_normalize, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, (int)nblk,
                            (const float*)scratch, adv);
         IMX_HIP(hipGetLastError());
@@ -130,7 +231,6 @@ extern "C" int imx_gae(int64_t T, int64_t N, const float* rew, const float* val,
 //   ratio  = exp(logp - old_logp); surrogate = max(-adv*ratio, -adv*clamp(ratio, 1-c, 1+c))
 //   value  = clipped: max((v-R)^2, (vo + clamp(v-vo,-c,c) - R)^2) ; else (R-v)^2
 // out4 = means over the minibatch.
-#define IMX_HALF_LOG_2PI 0.91893853320467274178f
 
 extern "C" size_t imx_ppo_scratch_bytes(int64_t M) { return ((size_t)((M + 255) / 256) * 4 + 8) * sizeof(float); }
 

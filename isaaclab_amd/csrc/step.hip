@@ -162,40 +162,7 @@ __global__ void k_action(PlanView P, int64_t N, const float* __restrict__ action
     if (i >= N * P.A) return;
     const int64_t e = i / P.A;
     const int c = (int)(i - e * P.A);
-    float a = actions[i];
-    if (pre_clip < __builtin_huge_valf()) a = fminf(fmaxf(a, -pre_clip), pre_clip);  // torch.clamp
-    Bf.prev_action[i] = Bf.action[i];
-    Bf.action[i] = a;
-    // find the term that owns column c (few terms; uniform loop)
-    for (int k = 0; k < P.nact; ++k) {
-        const int32_t* r = P.w + P.act_off + k * IMX_REC_WORDS;
-        const int o = r[IMX_R_OUT], d = r[IMX_R_DIM];
-        if (c < o || c >= o + d) continue;
-        const int j = c - o;
-        const int flags = r[IMX_R_FLAGS];
-        const float scale = r[IMX_R_AUX0] ? f_of(P.w[r[IMX_R_AUX0] + j]) : f_of(r[IMX_R_P0]);
-        float offset = r[IMX_R_AUX1] ? f_of(P.w[r[IMX_R_AUX1] + j]) : f_of(r[IMX_R_P1]);
-        const int jid = P.w[r[IMX_R_IDS_OFF] + j];
-        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) offset = S.default_joint_pos[e * P.J + jid];
-        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) offset = S.default_joint_vel[e * P.J + jid];
-        float v = (flags & IMX_F_ACT_EMA) ? a * scale : a * scale + offset;  // (an EMA term has no offset: the slot carries alpha)
-        if (flags & IMX_F_ACT_CLIP) {
-            const float lo = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j]), hi = f_of(P.w[r[IMX_R_IDS2_OFF] + 2 * j + 1]);
-            v = fminf(fmaxf(v, lo), hi);
-        }
-        if (flags & IMX_F_ACT_TO_LIMITS) {  // clamp(-1, 1), then unscale_transform (utils/math.py:43-61): x * (upper - lower) * 0.5 + (lower + upper) * 0.5
-            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
-            v = fminf(fmaxf(v, -1.0f), 1.0f);
-            v = v * (lim.y - lim.x) * 0.5f + (lim.x + lim.y) * 0.5f;
-        }
-        if (flags & IMX_F_ACT_EMA) {  // joint_actions_to_limits.py:219-230
-            const float2 lim = reinterpret_cast<const float2*>(S.soft_joint_pos_limits)[e * P.J + jid];
-            const float prev = (Bf.reset_buf && Bf.reset_buf[e]) ? S.joint_pos[e * P.J + jid] : Bf.processed_action[i];
-            v = offset * v + (1.0f - offset) * prev;
-            v = fminf(fmaxf(v, lim.x), lim.y);
-        }
-        Bf.processed_action[i] = v;
-    }
+    action_process_element(P, S, Bf, e, c, actions[i], pre_clip);
 }
 
 // The height scanner as a SensorBase (sensor_base.py:182-205,287-297; ray_caster.py:107-114,236-237): per-env timestamps decide whether
@@ -290,7 +257,15 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
             if (w < wv) wave_base += s_scan[w];
             total += s_scan[w];
         }
-        if (t == 0) Bf.counters[0] = total;  // number of reset envs
+        if (t == 0) {
+            Bf.counters[0] = total;  // number of reset envs
+            // the runner's ep_infos sum (imx_buffers.log_accum): this step's extras["log"] -- refreshed below when something was reset,
+            // the entries of the last refresh otherwise -- added to the running sum by the lane that owns the entry
+            if (Bf.log_accum) {
+                const int kc = P.nrew_all + P.nterm;
+                Bf.log_accum[kc] += total > 0 ? (float)total : Bf.log_out[kc];
+            }
+        }
         int off = wave_base + incl - local;
         for (int w = t * chunk; w < min((t + 1) * chunk, nw); ++w) {
             const int c = __builtin_nontemporal_load(&sc.wave_cnt[w]);
@@ -298,30 +273,39 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
                 Bf.reset_env_ids[off + j] = (int64_t)w * G + __builtin_nontemporal_load(&sc.ids_local[w * 64 + j]);
             off += c;
         }
-        if (total > 0 && t == 0) Bf.log_out[P.nrew_all + P.nterm] = (float)total;
+        if (total > 0 && t == 0) Bf.log_out[P.nrew_all + P.nterm] = (float)total;  // (after the read of the old value above: same lane)
         if (nparts > 1) return;
     } else {
         for (int w = lane; w < nw; w += 64) total += __builtin_nontemporal_load(&sc.wave_cnt[w]);
         total = wave_sum_i(total);
     }
-    if (total > 0) {  // reference only refreshes extras["log"] when something was reset (:216)
-        // one wave per log entry: lanes stride over the groups, fixed-shape shuffle tree -> deterministic
-        const int nlog = P.nrew_all + P.nterm;
-        const int first = nparts > 1 ? (part - 1) * NW + wv : wv, stride = nparts > 1 ? (nparts - 1) * NW : NW;
+    // reference only refreshes extras["log"] when something was reset (:216)
+    // one wave per log entry: lanes stride over the groups, fixed-shape shuffle tree -> deterministic
+    const int nlog = P.nrew_all + P.nterm;
+    const int first = nparts > 1 ? (part - 1) * NW + wv : wv, stride = nparts > 1 ? (nparts - 1) * NW : NW;
+    if (total > 0) {
         for (int k = first; k < nlog; k += stride) {
+            float v;
             if (k < P.nrew_all) {
                 float s = 0.0f;
                 for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.log_part[(size_t)w * P.nrew_all + k]);
                 s = wave_sum(s);
-                if (lane == 0) Bf.log_out[k] = s / (float)total / P.max_ep_len_s;
+                v = s / (float)total / P.max_ep_len_s;
             } else {
                 const int kt = k - P.nrew_all;
                 int s = 0;
                 for (int w = lane; w < nw; w += 64) s += __builtin_nontemporal_load(&sc.term_part[(size_t)w * P.nterm + kt]);
                 s = wave_sum_i(s);
-                if (lane == 0) Bf.log_out[k] = (float)s;
+                v = (float)s;
+            }
+            if (lane == 0) {
+                Bf.log_out[k] = v;
+                if (Bf.log_accum) Bf.log_accum[k] += v;
             }
         }
+    } else if (Bf.log_accum) {
+        for (int k = first; k < nlog; k += stride)
+            if (lane == 0) Bf.log_accum[k] += Bf.log_out[k];
     }
 }
 
@@ -342,7 +326,8 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
 // with a square root each (9.7 us for undesired_contacts against 2 us for a joint sum) -- hence exact trip counts and one square
 // root per body (max_hist_force), and the end of the step moved out of the kernel (step_tail: 4.9 us of fence + ticket).
 __global__ void __launch_bounds__(64 * IMX_TR_MAX_WAVES)
-k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame, int G, int defer_tail) {
+k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch sc, float* __restrict__ frame, int G, int defer_tail,
+           imx_rollout_slot_t ro) {
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -370,6 +355,11 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
     // -- phase 0: everything that needs no table is issued at once: root state, and the episodic sum of this wave's first reward item
     const int first_rew = wv >= nterm ? wv - nterm : wv - nterm + ((nterm - wv + NW - 1) / NW) * NW;  // first item >= nterm of this wave
     const float es_first = (live && first_rew < nrew) ? Bf.episode_sums[(size_t)first_rew * N + e] : 0.0f;
+    // slot t of the rollout storage (imx_terminations_rewards_rollout): what wave 0 needs at the very end is requested now
+    const bool ro_on = ro.rewards_out != nullptr && wv == 0 && live;
+    const float ro_value = ro_on ? ro.value_t[e] : 0.0f;
+    const float ro_cur_rew = (ro_on && ro.cur_reward_sum) ? ro.cur_reward_sum[e] : 0.0f;
+    const float ro_cur_len = (ro_on && ro.cur_ep_len) ? ro.cur_ep_len[e] : 0.0f;
     const float4 q4 = reinterpret_cast<const float4*>(S.root_quat_w)[ec];
     const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
     const float lwx = S.root_lin_vel_w[ec * 3], lwy = S.root_lin_vel_w[ec * 3 + 1], lwz = S.root_lin_vel_w[ec * 3 + 2];
@@ -638,6 +628,28 @@ k_term_rew(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, StepScratch s
                     Bf.action[e * A + i] = 0.0f;
                     Bf.prev_action[e * A + i] = 0.0f;
                 }
+        }
+        // slot t of the RolloutStorage (what imx_rollout_post does in a launch of its own): RslRlVecEnvWrapper.step's dones
+        // (vecenv_wrapper.py:178), PPO.process_env_step's time-out bootstrap, the runner's episode book-keeping -- same expressions,
+        // bit-identical
+        if (ro.rewards_out) {
+            float s_r = 0.0f, s_l = 0.0f, s_c = 0.0f;
+            if (live) {
+                ro.rewards_out[e] = ro.bootstrap_time_outs ? reward + ro.gamma * (ro_value * (truncated ? 1.0f : 0.0f)) : reward;
+                ro.dones_out[e] = reset ? 1 : 0;
+                if (ro.cur_reward_sum) {
+                    const float cr = ro_cur_rew + reward, cl = ro_cur_len + 1.0f;
+                    if (reset) { s_r = cr; s_l = cl; s_c = 1.0f; }
+                    ro.cur_reward_sum[e] = reset ? 0.0f : cr;
+                    ro.cur_ep_len[e] = reset ? 0.0f : cl;
+                }
+            }
+            if (ro.ep_stats3) {
+                s_r = wave_sum(s_r); s_l = wave_sum(s_l); s_c = wave_sum(s_c);
+                if (lane == 0 && s_c > 0.0f) {
+                    atomicAdd(&ro.ep_stats3[0], s_r); atomicAdd(&ro.ep_stats3[1], s_l); atomicAdd(&ro.ep_stats3[2], s_c);
+                }
+            }
         }
         // ordered compaction inside the group: reset_env_ids = reset_buf.nonzero() (manager_based_rl_env.py:215)
         const unsigned long long ballot = __ballot(reset);
@@ -1144,18 +1156,24 @@ static int check_common(const imx_plan_t* plan, int64_t N, const imx_state_t* st
     return 0;
 }
 
+int imx_check_action_inputs(const imx_plan_t* plan, const imx_state_t* st, const imx_buffers_t* bf, const char* who) {
+    IMX_REQUIRE(bf->action && bf->prev_action && bf->processed_action, "%s: null action buffer", who);
+    IMX_REQUIRE(plan->A > 0, "%s: plan has no action columns", who);
+    for (int k = 0; k < plan->nact; ++k) {
+        const int flags = plan->host[plan->act_off + k * IMX_REC_WORDS + IMX_R_FLAGS];
+        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) IMX_REQUIRE(st->default_joint_pos, "%s: default_joint_pos missing", who);
+        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) IMX_REQUIRE(st->default_joint_vel, "%s: default_joint_vel missing", who);
+        if (flags & (IMX_F_ACT_TO_LIMITS | IMX_F_ACT_EMA)) IMX_REQUIRE(st->soft_joint_pos_limits, "%s: soft_joint_pos_limits missing", who);
+        if (flags & IMX_F_ACT_EMA) IMX_REQUIRE(st->joint_pos, "%s: joint_pos missing", who);
+    }
+    return 0;
+}
+
 extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float* actions_d, float pre_clip,
                                   const imx_state_t* st, const imx_buffers_t* bf, imx_stream_t stream) {
     if (check_common(plan, N, st, bf)) return 1;
-    IMX_REQUIRE(actions_d && bf->action && bf->prev_action && bf->processed_action, "imx_action_process: null buffer");
-    IMX_REQUIRE(plan->A > 0, "imx_action_process: plan has no action columns");
-    for (int k = 0; k < plan->nact; ++k) {
-        const int flags = plan->host[plan->act_off + k * IMX_REC_WORDS + IMX_R_FLAGS];
-        if (flags & IMX_F_ACT_DEFAULT_POS_OFFSET) IMX_REQUIRE(st->default_joint_pos, "default_joint_pos missing");
-        if (flags & IMX_F_ACT_DEFAULT_VEL_OFFSET) IMX_REQUIRE(st->default_joint_vel, "default_joint_vel missing");
-        if (flags & (IMX_F_ACT_TO_LIMITS | IMX_F_ACT_EMA)) IMX_REQUIRE(st->soft_joint_pos_limits, "soft_joint_pos_limits missing");
-        if (flags & IMX_F_ACT_EMA) IMX_REQUIRE(st->joint_pos, "joint_pos missing");
-    }
+    IMX_REQUIRE(actions_d, "imx_action_process: null actions");
+    if (imx_check_action_inputs(plan, st, bf, "imx_action_process")) return 1;
     const int64_t n = N * plan->A;
     const int bs = 256;
     hipLaunchKernelGGL(k_action, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream,
@@ -1166,7 +1184,19 @@ extern "C" int imx_action_process(const imx_plan_t* plan, int64_t N, const float
 
 extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const imx_state_t* st,
                                         const imx_buffers_t* bf, int flags, imx_stream_t stream) {
+    return imx_terminations_rewards_rollout(plan, N, st, bf, flags, nullptr, stream);
+}
+
+extern "C" int imx_terminations_rewards_rollout(const imx_plan_t* plan, int64_t N, const imx_state_t* st, const imx_buffers_t* bf,
+                                                int flags, const imx_rollout_slot_t* slot, imx_stream_t stream) {
     if (check_common(plan, N, st, bf)) return 1;
+    imx_rollout_slot_t ro{};
+    if (slot) {
+        ro = *slot;
+        IMX_REQUIRE(ro.value_t && ro.rewards_out && ro.dones_out, "imx_terminations_rewards_rollout: value_t, rewards_out and dones_out are required");
+        IMX_REQUIRE((ro.cur_reward_sum == nullptr) == (ro.cur_ep_len == nullptr), "imx_terminations_rewards_rollout: episode buffers come together");
+        IMX_REQUIRE(!ro.ep_stats3 || ro.cur_reward_sum, "imx_terminations_rewards_rollout: ep_stats3 needs the episode buffers");
+    }
     IMX_REQUIRE(st->root_quat_w && st->root_lin_vel_w && st->root_ang_vel_w, "root state missing");
     IMX_REQUIRE(bf->episode_length_buf && bf->reward_buf && bf->episode_sums && bf->step_reward && bf->term_dones &&
                     bf->terminated && bf->truncated && bf->reset_buf && bf->reset_env_ids && bf->counters &&
@@ -1228,9 +1258,38 @@ extern "C" int imx_terminations_rewards(const imx_plan_t* plan, int64_t N, const
     // with the root position at hand the kernel also leaves the frame table imx_observations needs (flag 4 there skips k_frame)
     float* frame = st->root_pos_w ? reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N)) : nullptr;
     hipLaunchKernelGGL(k_term_rew, dim3(grid), dim3(64 * NW), lds, (hipStream_t)stream, imx_plan_view(plan), N, *st, *bf, sc, frame, G,
-                       flags & 1);
+                       flags & 1, ro);
     IMX_HIP(hipGetLastError());
     return 0;
+}
+
+// Which observation kernel a plan gets (imx_observations below; imx_observations_kernel_name reports it to benchmarks).
+struct ObsKernelChoice {
+    bool lean;         // one group, no modifier programs, no history windows, no gaussian noise (DC == D also rules out twin scan columns)
+    bool vertical;     // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
+    bool single_wave;  // k_obs_lean: one single-wave workgroup per 64 rays + one for the env's other columns
+    int scan_rec;
+};
+static ObsKernelChoice choose_obs_kernel(const imx_plan_t* plan) {
+    const auto& w = plan->host;
+    const PlanView pv = imx_plan_view(plan);
+    ObsKernelChoice c;
+    c.lean = plan->ngroups == 1 && plan->MS == 0 && plan->DC == plan->D && plan->DX == plan->DC;
+    for (int k = 0; k < plan->nobs && c.lean; ++k) c.lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & (IMX_F_MODIFIERS | IMX_F_NOISE_GAUSS));
+    c.vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
+    c.scan_rec = -1;
+    for (int k = 0; k < plan->nobs; ++k)
+        if (w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) c.scan_rec = k;
+    c.single_wave = c.lean && c.scan_rec >= 0 && pv.R > 0 && pv.R <= 64 * 15;
+    return c;
+}
+
+extern "C" const char* imx_observations_kernel_name(const imx_plan_t* plan) {
+    if (!plan) return "";
+    const ObsKernelChoice c = choose_obs_kernel(plan);
+    if (c.single_wave) return c.vertical ? "k_obs_lean<false>" : "k_obs_lean<true>";
+    if (c.vertical) return c.lean ? "k_obs<false,true>" : "k_obs<false,false>";
+    return c.lean ? "k_obs<true,true>" : "k_obs<true,false>";
 }
 
 extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_state_t* st, const imx_buffers_t* bf,
@@ -1280,8 +1339,8 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     float* frame = reinterpret_cast<float*>(reinterpret_cast<char*>(bf->scratch) + frame_offset_bytes(plan, N));
     if (!(enable_corruption & 4))  // bit 2: imx_terminations_rewards ran on this very state and left the frame table behind
         hipLaunchKernelGGL(k_frame, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pv, N, *st, *bf, frame, (enable_corruption >> 1) & 1);
-    // height-scanner frame yaw-only + vertical direction (the reference cfg): register-lean single-cell ray path
-    const bool vertical = pv.R == 0 || (pv.ray_yaw_only && pv.rdx == 0.0f && pv.rdy == 0.0f && pv.rdz != 0.0f);
+    const ObsKernelChoice ch = choose_obs_kernel(plan);
+    const bool vertical = ch.vertical;
     // bit 4: finish the step tail imx_terminations_rewards (flags bit 0) left to this call -- one extra workgroup
     const bool tail = (enable_corruption & 16) != 0;
     StepScratch sc{};
@@ -1293,16 +1352,12 @@ extern "C" int imx_observations(const imx_plan_t* plan, int64_t N, const imx_sta
     }
     const size_t lds = (size_t)(pv.R > 0 ? pv.R : 1) * 4;
     const int nlog = plan->nrew_all + plan->nterm;
-    // the lean variant: one group, no modifier programs, no history windows (DC == D also rules out twin scan columns)
-    bool lean = plan->ngroups == 1 && plan->MS == 0 && plan->DC == plan->D && plan->DX == plan->DC;
-    for (int k = 0; k < plan->nobs && lean; ++k) lean = !(w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_FLAGS] & (IMX_F_MODIFIERS | IMX_F_NOISE_GAUSS));
+    const bool lean = ch.lean;
 #define IMX_LAUNCH_OBS(G, L)                                                                                                     \
     hipLaunchKernelGGL((k_obs<G, L>), dim3(grid), dim3(bs), lds, (hipStream_t)stream, pv, N, *st, *bf, mv, frame, noise_u_d, seed, \
                        enable_corruption, ray_hits_out_d, sc, tail_G, tail_parts)
-    int scan_rec = -1;
-    for (int k = 0; k < plan->nobs; ++k)
-        if (w[plan->obs_off + k * IMX_REC_WORDS + IMX_R_OP] == IMX_O_HEIGHT_SCAN) scan_rec = k;
-    if (lean && scan_rec >= 0 && pv.R > 0 && pv.R <= 64 * 15) {
+    const int scan_rec = ch.scan_rec;
+    if (ch.single_wave) {
         // one single-wave workgroup per 64 rays + one for the env's other columns
         const int wpe = (pv.R + 63) / 64 + 1;
         IMX_REQUIRE((uint64_t)N * wpe + 1 < (1ull << 31), "imx_observations: %lld envs x %d waves exceed the grid", (long long)N, wpe);

@@ -882,7 +882,7 @@ class ManagerBasedRLEnv:
                                            ctypes.byref(self._bufs), _lib.current_stream(self.device)))
 
     def _eval_external(self, kind: str):
-        for col, (term, fn) in enumerate(self._ext_funcs[kind]):
+        for col, (term, fn) in enumerate(self._ext_funcs[kind] if kind != "obs" else ()):  # (each term is called ONCE per step: class terms keep state)
             if kind == "rew" and term.weight == 0.0:
                 continue  # reward_manager.py:145: a zero-weight term is not evaluated
             val = fn(self, **term.call_params)
@@ -950,6 +950,12 @@ class ManagerBasedRLEnv:
         """ManagerBasedRLEnv.step (manager_based_rl_env.py:153-242)."""
         # -- pre-physics
         self._process_action(action)
+        return self._step_after_action()
+
+    def _step_after_action(self, rollout_slot=None):
+        """``step()`` from the physics on.  The fused rollout (rsl_rl/runner.py) enters here: its actor kernel has already run the
+        sampled action through the action terms (imx_mlp_infer_act), and ``rollout_slot`` (an ``ImxRolloutSlot``) makes the step kernel
+        write slot t of the RolloutStorage itself (imx_terminations_rewards_rollout)."""
         # -- physics (decimation x sim.step) is replaced by the feed moving to its next recorded state
         self._sim_step_counter += int(self.cfg_decimation)
         self.feed.advance()
@@ -964,8 +970,10 @@ class ManagerBasedRLEnv:
         # flag 1: the end of the step (ordered reset ids, reset count, Episode_* log) is finished by an extra workgroup of the
         # observation kernel below -- same stream, kernel boundary in between -- instead of a fence + ticket in this launch
         self._bufs.scan_drift_feed = _lib.ptr(self._scan_drift_feed)  # the step kernel advances the sensor clock (resets draw a drift)
-        check(self._lib.imx_terminations_rewards(self._plan_h, self.num_envs, ctypes.byref(self._state()),
-                                                 ctypes.byref(self._bufs), 1 if self.defer_step_tail else 0, _lib.current_stream(self.device)))
+        check(self._lib.imx_terminations_rewards_rollout(self._plan_h, self.num_envs, ctypes.byref(self._state()), ctypes.byref(self._bufs),
+                                                         1 if self.defer_step_tail else 0,
+                                                         ctypes.byref(rollout_slot) if rollout_slot is not None else None,
+                                                         _lib.current_stream(self.device)))
         self.extras["log"] = self._log_views
         if self._class_terms:
             # _reset_idx reaches the class terms between the reward and the observation pass (manager_based_rl_env.py:215-218 ->

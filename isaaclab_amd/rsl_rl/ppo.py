@@ -183,12 +183,15 @@ class FusedInference:
         for buf, w in self._padded:
             buf[:, :w.shape[1]].copy_(w)
 
-    def __call__(self, x: torch.Tensor, *outs: torch.Tensor):
-        if x.stride(1) != 1 or x.shape[1] != self.in_features or any(not o.is_contiguous() for o in outs):
+    def __call__(self, x: torch.Tensor, *outs: torch.Tensor, act=None):
+        """``act``: an ``ImxPolicyAct`` -- the actor's workgroups then also sample the action, write the transition into the storage
+        slot it names and run the action through the env's action terms (``imx_mlp_infer_act``); ``outs[0]`` may be None then."""
+        if x.stride(1) != 1 or x.shape[1] != self.in_features or any(o is not None and not o.is_contiguous() for o in outs):
             raise _lib.ImxError("imx_mlp_infer needs a row-major input and contiguous outputs")
-        out_p = (self._ctypes.c_void_p * self._n)(*[o.data_ptr() for o in outs])
-        check(lib().imx_mlp_infer(x.shape[0], x.data_ptr(), x.stride(0), self._n, self._nl, self._dims, self._w, self._pitch, self._b,
-                                  self._alpha, out_p, _lib.current_stream(x.device)))
+        out_p = (self._ctypes.c_void_p * self._n)(*[None if o is None else o.data_ptr() for o in outs])
+        check(lib().imx_mlp_infer_act(x.shape[0], x.data_ptr(), x.stride(0), self._n, self._nl, self._dims, self._w, self._pitch, self._b,
+                                      self._alpha, out_p, self._ctypes.byref(act) if act is not None else None,
+                                      _lib.current_stream(x.device)))
 
 
 HEAD_MAX_OUT = 64  # imx_mlp_head_*: output layers up to 64 wide (action means, value)

@@ -191,11 +191,20 @@ class OnPolicyRunner:
             self._obs_out.copy_(obs)
         return obs
 
+    fuse_launches = True  # False: the round-2 split (imx_mlp_infer, imx_policy_act, imx_action_process, ..., imx_rollout_post: 6 launches per step)
+
     def _rollout_fused(self):
-        """Per step: 2 MLP forwards (torch GEMMs) + imx_policy_act + the 4 env kernels + imx_rollout_post; every
-        transition is written straight into its storage slot (no Transition object, no per-field copies)."""
+        """Per step THREE launches: ``imx_mlp_infer_act`` (both MLPs + PPO.act's sampling / log-prob / transition writes + the
+        ActionManager's action processing in the actor head's epilogue), ``imx_terminations_rewards_rollout`` (terminations, rewards,
+        resets + the wrapper's dones, the time-out bootstrap and the episode statistics into slot t) and ``imx_observations`` (+ the
+        step tail and the log accumulation).  Every transition is written straight into its storage slot.  Envs with a privileged
+        ("critic") observation group, Python-evaluated terms aside, take the split path (``fuse_launches = False``), which produces
+        bit-identical storage contents (tests/test_kernels_gpu.py)."""
+        import ctypes
+        import math
+
         from .. import _lib
-        from .._lib import check, lib
+        from .._lib import ImxPolicyAct, ImxRolloutSlot, check, lib
         from .ppo import mlp_forward
 
         L = lib()
@@ -218,6 +227,26 @@ class OnPolicyRunner:
                 self._infer = FusedInference(alg._actor_layers, alg._critic_layers) if priv is None else _NoFusedInference()
                 self._mu_buf = torch.empty(N, A, device=self.device)
                 self._value_buf = torch.empty(N, 1, device=self.device)
+            fused = self.fuse_launches and self._infer.ok and priv is None and obs.is_contiguous() and obs.shape[1] == D
+            if fused:
+                # launch 1: actor + critic + PPO.act + ActionManager.process_action
+                act = ImxPolicyAct(std_d=pol.std.data_ptr(), seed=self._act_seed, step_counter_d=step_ptr,
+                                   actions_out_d=st.actions[t].data_ptr(), logp_out_d=st.actions_log_prob[t].data_ptr(),
+                                   mu_out_d=st.mu[t].data_ptr(), sigma_out_d=st.sigma[t].data_ptr(), obs_out_d=st.observations[t].data_ptr(),
+                                   plan=env._plan_h.value, state=ctypes.pointer(env._state()), buf=ctypes.pointer(env._bufs),
+                                   pre_clip=math.inf if env.clip_actions is None else float(env.clip_actions))
+                self._infer(obs, None, st.values[t], act=act)
+                # launch 2 (+ launch 3, the observations): the step kernel writes slot t itself; the log sum rides in the step tail
+                slot = ImxRolloutSlot(value_t=st.values[t].data_ptr(), rewards_out=st.rewards[t].data_ptr(), dones_out=st.dones[t].data_ptr(),
+                                      cur_reward_sum=self._cur_reward_sum.data_ptr(), cur_ep_len=self._cur_episode_length.data_ptr(),
+                                      ep_stats3=self._ep_stats.data_ptr(), gamma=float(alg.gamma), bootstrap_time_outs=bootstrap)
+                env._bufs.log_accum = self._log_accum.data_ptr()
+                try:
+                    obs_dict = env._step_after_action(slot)[0]
+                finally:
+                    env._bufs.log_accum = None
+                obs = obs_dict["policy"]
+                continue
             if self._infer.ok:  # both networks, all layers, one launch (activations stay in LDS)
                 mu, value = self._mu_buf, self._value_buf
                 self._infer(obs, mu, value)

@@ -24,7 +24,7 @@ def gae_returns(rewards, values, dones, last_values, gamma: float, lam: float, n
         advantages = torch.empty_like(rewards)
     L = lib()
     if scratch is None:
-        scratch = torch.empty(int(L.imx_gae_scratch_bytes(T, N)), dtype=torch.uint8, device=dev)
+        scratch = torch.zeros(int(L.imx_gae_scratch_bytes(T, N)), dtype=torch.uint8, device=dev)
     if dones.dtype not in (torch.uint8, torch.bool):
         raise TypeError("dones must be uint8/bool")
     check(L.imx_gae(T, N, _lib.ptr(rewards), _lib.ptr(values), _lib.ptr(dones), _lib.ptr(last_values), float(gamma),
@@ -91,7 +91,7 @@ class RolloutStorage:
     def compute_returns(self, last_values, gamma, lam, normalize_advantage: bool = True):
         if self._gae_scratch is None:
             n = int(lib().imx_gae_scratch_bytes(self.num_transitions_per_env, self.num_envs))
-            self._gae_scratch = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._gae_scratch = torch.zeros(n, dtype=torch.uint8, device=self.device)  # (barrier counters start at zero)
         gae_returns(self.rewards, self.values, self.dones, last_values.contiguous(), gamma, lam, normalize_advantage,
                     self.returns, self.advantages, self._gae_scratch)
 

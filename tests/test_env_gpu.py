@@ -458,6 +458,73 @@ def test_fused_rollout_storage_is_self_consistent(use_graph):
     assert batch[1] is batch[0] and float(batch[0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("case", ["flat-64-graph", "flat-64-eager", "rough-4096", "flat-2500-clip"])
+def test_three_launch_rollout_step_equals_the_six_launch_split(case):
+    """imx_mlp_infer_act (MLPs + PPO.act + ActionManager.process_action) and imx_terminations_rewards_rollout (+ the wrapper's dones,
+    the time-out bootstrap, episode statistics; log sum in the step tail) against the split launches of round 2 (imx_mlp_infer,
+    imx_policy_act, imx_action_process, imx_terminations_rewards, imx_observations, imx_rollout_post): two collects from identical
+    states must leave BIT-IDENTICAL storages and env buffers.  64 envs take the 16-sample inference tiles, 2500 / 4096 the 32-sample
+    ones (2500: a ragged last tile); one case clips the actions (RslRlVecEnvWrapper clip_actions)."""
+    import copy
+
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
+    from isaaclab_amd.robots import ROBOTS
+    from isaaclab_amd.state_feed import StateFeed
+
+    def build(fuse):
+        torch.manual_seed(3)
+        if case.startswith("flat-64"):
+            g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+            env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), noise_seed=11)
+            agent, T = g.fixture["agent"], 8
+        else:
+            task = "Isaac-Velocity-Rough-Anymal-C-v0" if case.startswith("rough") else "Isaac-Velocity-Flat-Anymal-C-v0"
+            g = Golden(task)
+            N = 4096 if case.startswith("rough") else 2500
+            mesh = g.mesh()
+            ext = None
+            if mesh is not None:
+                ext = (float(np.abs(mesh[0][:, 0]).max()) - 2.0, float(np.abs(mesh[0][:, 1]).max()) - 2.0)
+            feed = StateFeed(ROBOTS[g.fixture["robot"]], N, "cuda:0", seed=5, num_snapshots=4, extent_xy=ext)
+            env = ManagerBasedRLEnv(g.fixture, state_feed=feed, terrain=mesh, noise_seed=11)
+            agent, T = g.fixture["agent"], 4
+        venv = RslRlVecEnvWrapper(env, clip_actions=0.8 if case.endswith("clip") else None)
+        runner = OnPolicyRunner(venv, dict(agent, num_steps_per_env=T), log_dir=None, device="cuda:0", use_graph=case.endswith("graph"))
+        runner.fuse_launches = fuse
+        runner.train_mode()
+        gen = torch.Generator().manual_seed(9)
+        ep = torch.randint(0, int(venv.max_episode_length), (env.num_envs,), generator=gen)
+        ep[::7] = int(venv.max_episode_length) - 2  # time-outs inside the rollout: the bootstrap term is exercised
+        venv.episode_length_buf = ep.cuda()
+        return env, runner
+
+    out = {}
+    for fuse in (False, True):
+        env, runner = build(fuse)
+        assert runner._fusable()
+        for _ in range(2):  # with use_graph the second collect is a replay
+            runner.collect()
+        torch.cuda.synchronize()
+        st = runner.alg.storage
+        out[fuse] = {k: getattr(st, k).clone() for k in ("observations", "actions", "actions_log_prob", "mu", "sigma", "values", "rewards", "dones")}
+        out[fuse].update(action=env._action.clone(), prev_action=env._prev_action.clone(), processed=env._processed_action.clone(),
+                         cur_rew=runner._cur_reward_sum.clone(), cur_len=runner._cur_episode_length.clone(), last_obs=runner.last_obs.clone(),
+                         ep_len=env.episode_length_buf.clone(), reset_ids=env.reset_env_ids.clone(), log_out=env._log_out.clone())
+        out[fuse]["ep_stats"], out[fuse]["log_accum"] = runner._ep_stats.clone(), runner._log_accum.clone()
+        env.close()
+    a, b = out[False], out[True]
+    for k in a:
+        if k in ("ep_stats", "log_accum"):
+            continue
+        assert torch.equal(a[k], b[k]), f"{k}: fused and split rollouts differ"
+    assert float(a["dones"].sum()) > 0 and float(a["log_accum"].abs().sum()) > 0
+    assert torch.equal(a["log_accum"], b["log_accum"]), "per-iteration log sums"
+    assert_close(b["ep_stats"], a["ep_stats"], 1e-5, "finished-episode statistics (float atomics: order differs)")
+    if case.endswith("clip"):
+        assert float(b["action"].abs().max()) <= float(np.float32(0.8))
+
+
 @pytest.mark.gpu
 def test_frame_table_from_the_step_kernel_equals_k_frame():
     """env.step() lets imx_terminations_rewards leave the per-env frame table (root-frame vectors, scanner yaw) for imx_observations

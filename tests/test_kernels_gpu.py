@@ -97,8 +97,9 @@ def test_raycast_matches_brute_force_oracles():
     assert mesh.raycast(e, e)[0].shape == (0, 3)
 
 
-@pytest.mark.parametrize("T,N", [(24, 4096), (16, 64), (5, 1), (24, 100_001)])
+@pytest.mark.parametrize("T,N", [(24, 4096), (16, 64), (5, 1), (24, 100_001), (40, 300), (32, 16_384), (24, 16_385)])
 def test_gae_matches_rsl_rl_restatement(libimx, T, N):
+    """(T <= 32 and N <= 64 x #CUs: the single-launch kernel with the grid barrier; otherwise scan + normalisation kernels.)"""
     from isaaclab_amd.rsl_rl.storage import gae_returns
     from oracle.rsl_rl_oracle import compute_returns
 
@@ -119,6 +120,13 @@ def test_gae_matches_rsl_rl_restatement(libimx, T, N):
     nv = torch.cat([val[1:], last.unsqueeze(0)], 0)
     td = rew + (1 - dones.float()) * 0.9 * nv - val
     assert_close(adv, td, FLOAT_TOL, "TD(0)")
+    # the same scratch block over many calls (the storage keeps one): the grid-barrier counters re-arm, results repeat bit for bit
+    scr = torch.zeros(int(libimx.imx_gae_scratch_bytes(T, N)), dtype=torch.uint8, device="cuda")
+    args = (rew.cuda(), val.cuda(), dones.cuda(), last.cuda(), 0.99, 0.95, True)
+    ret_a, adv_a = (x.clone() for x in gae_returns(*args, scratch=scr))
+    for _ in range(5):
+        ret_b, adv_b = gae_returns(*args, scratch=scr)
+        assert torch.equal(ret_a, ret_b) and torch.equal(adv_a, adv_b)
 
 
 @pytest.mark.parametrize("M,A", [(24576, 12), (1000, 37), (7, 1)])
