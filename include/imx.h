@@ -212,7 +212,8 @@ typedef struct imx_buffers {
     int32_t* counters;           /* (8) [0] reset count [1] ticket [2] step counter (RNG streams, sensor stamps): imx_terminations_rewards
                                     publishes [3] + 1 there [3] its shadow, written by imx_observations (a step = one of each)
                                     [4],[5] low / high word of the sensor-drift seed (caller-written) [6..] reserved */
-    float* log_out;              /* (NREW_ALL + NTERM + 1) Episode_Reward/<term>, Episode_Termination/<term>, count */
+    float* log_out;              /* (NREW_ALL + NTERM + 1 + 3) Episode_Reward/<term>, Episode_Termination/<term>, count, then the three
+                                    orchestration entries (see ev_part) */
     float* obs;                  /* (N,D_0) first observation group; managers/observation_manager.py:238-335 */
     void* scratch;               /* imx_plan_scratch_bytes(plan, N) bytes */
     float* mod_state;            /* (N, IMX_H_MOD_STATE) DigitalFilter / Integrator state; NULL when the plan has none */
@@ -231,6 +232,12 @@ typedef struct imx_buffers {
                                     mean of extras["log"] (upstream on_policy_runner.py: ep_infos.append(infos["log"]) every step; the
                                     dict is only REFRESHED on steps that reset something, manager_based_rl_env.py:216, so a step without
                                     resets adds the entries of the last refresh again).  Updated where log_out is (the step tail) */
+    const float* ev_part;        /* optional: imx_orch_t.ev_part_d of the imx_reset_orchestrate launch between imx_terminations_rewards and
+                                    imx_observations -- the step tail then also writes log_out[NREW_ALL + NTERM + 1 ..]: the two
+                                    Metrics/<command>/error_vel_xy|yaw entries (command_manager.py:123-149: means over the reset envs) and
+                                    Curriculum/terrain_levels (curriculum_manager.py:95-118: mean level over all envs); needs the deferred
+                                    tail (flags bit 0 / enable_corruption bit 4) */
+    int64_t ev_flags;            /* bit 0: the metrics entries exist, bit 1: the curriculum entry exists */
 } imx_buffers_t;
 
 /* ---- slot t of an rsl_rl RolloutStorage, filled by the step kernel itself (imx_terminations_rewards_rollout) ------------------ */
@@ -245,9 +252,112 @@ typedef struct imx_rollout_slot {
     int32_t bootstrap_time_outs; /* 0 for a finite-horizon task (vecenv_wrapper.py:184-185: no "time_outs" key) */
 } imx_rollout_slot_t;
 
+/* ---- the reset / interval orchestration around the step (imx_reset_orchestrate) ------------------------------------------------
+ * ManagerBasedRLEnv._reset_idx (envs/manager_based_rl_env.py:347-392) for the envs the step reset -- CurriculumManager.compute
+ * (terrain_levels_vel + TerrainImporter.update_env_origins), scene.reset (contact sensor, actuator state), EventManager.apply("reset")
+ * with min_step_count_between_reset (managers/event_manager.py:233-260), CommandTerm.reset (metrics for the log, resample) -- followed by
+ * what ManagerBasedRLEnv.step does next (:232-236): CommandManager.compute(dt) and EventManager.apply("interval", dt) with per-env or
+ * global timers re-sampled in the kernel (event_manager.py:205-232).  One lane per env, ONE launch, no host read: the reference walks
+ * nonzero() id lists with a host sync per interval term and per manager reset. */
+#define IMX_ORCH_MAX_TERMS 8
+enum imx_event_op {
+    IMX_E_RESET_ROOT_STATE_UNIFORM = 1, /* envs/mdp/events.py:823-868;  ranges: pose lo/hi x 6 [0..11], velocity lo/hi x 6 [12..23] */
+    IMX_E_RESET_JOINTS_BY_SCALE,        /* :987-1015;  ranges: position lo, hi, velocity lo, hi */
+    IMX_E_RESET_JOINTS_BY_OFFSET,       /* :1020-1049 */
+    IMX_E_PUSH_BY_SETTING_VELOCITY,     /* :795-820;   ranges: lo/hi x 6 */
+    IMX_E_APPLY_EXTERNAL_FORCE_TORQUE   /* :764-791;   ranges: force lo, hi, torque lo, hi; body ids */
+};
+typedef struct imx_event_term {
+    int32_t op;                            /* enum imx_event_op */
+    int32_t mode;                          /* 0 = "reset", 1 = "interval" (EventTermCfg.mode) */
+    int32_t is_global_time;                /* interval terms: one timer for all envs (event_manager.py:213-221) */
+    int32_t min_step_count_between_reset;  /* reset terms (:233-260) */
+    float interval_lo, interval_hi;        /* interval_range_s */
+    float ranges[24];
+    int32_t num_body_ids;
+    int32_t reserved;
+    const int32_t* body_ids_d;             /* IMX_E_APPLY_EXTERNAL_FORCE_TORQUE: resolved body ids (NULL = all bodies) */
+    int32_t* last_triggered_step_d;        /* (N) reset terms: _reset_term_last_triggered_step_id */
+    uint8_t* triggered_once_d;             /* (N) reset terms: _reset_term_last_triggered_once */
+    float* time_left_d;                    /* interval terms: (N) per-env timers, or (2) for a global timer -- slot [step & 1] is read,
+                                              slot [(step + 1) & 1] written (no read-modify-write race across workgroups) */
+    const float* uniforms_d;               /* optional (N, width) samples in [0,1) replacing the in-kernel draws (parity runs); width =
+                                              12 (root state), 2J (joints), 6 (push), 6 x bodies (wrench: forces first) */
+    const float* interval_uniforms_d;      /* optional (N) samples for the timer re-sampling (a global timer takes [0]) */
+} imx_event_term_t;
+
+typedef struct imx_orch {
+    int64_t num_envs, num_joints, num_bodies;
+    const uint8_t* reset_mask_d;           /* (N) imx_buffers.reset_buf of this step; NULL = every env (ManagerBasedEnv.reset) */
+    const int32_t* step_counter_d;         /* the global env step count on the device (_sim_step_counter // decimation): buf->counters + 2 */
+    uint64_t seed;
+    float dt;                              /* step_dt */
+    int32_t do_step;                       /* 1: inside step() -- CommandManager.compute + interval events follow the resets; 0: reset() */
+    int32_t num_terms;
+    int32_t reserved0;
+    imx_event_term_t terms[IMX_ORCH_MAX_TERMS];   /* cfg order */
+    /* the asset: defaults, limits, the current (post-physics) root state */
+    const float* default_root_state_d;     /* (N,13) */
+    const float* default_joint_pos_d;      /* (N,J) */
+    const float* default_joint_vel_d;
+    const float* soft_joint_pos_limits_d;  /* (N,J,2) */
+    const float* soft_joint_vel_limits_d;  /* (N,J) */
+    const float* root_pos_w_d;             /* (N,3) */
+    const float* root_quat_w_d;            /* (N,4) */
+    const float* root_lin_vel_w_d;         /* (N,3) */
+    const float* root_ang_vel_w_d;         /* (N,3) */
+    float* env_origins_d;                  /* (N,3) scene.env_origins: read by the events, updated by the curriculum */
+    /* what write_root_pose_to_sim / write_root_velocity_to_sim / write_joint_state_to_sim / set_external_force_and_torque receive */
+    float* root_pose_out_d;                /* (N,7) */
+    float* root_vel_out_d;                 /* (N,6) */
+    float* joint_pos_out_d;                /* (N,J) */
+    float* joint_vel_out_d;                /* (N,J) */
+    float* ext_force_out_d;                /* (N,NB,3) */
+    float* ext_torque_out_d;               /* (N,NB,3) */
+    /* CurriculumManager: terrain_levels_vel (isaaclab_tasks/.../velocity/mdp/curriculums.py:26-55); NULL terrain_levels_d = none */
+    const float* terrain_origins_d;        /* (R,C,3) */
+    const int64_t* terrain_types_d;        /* (N) */
+    int64_t* terrain_levels_d;             /* (N) */
+    const int64_t* rand_levels_d;          /* optional (N): the randint_like draw (parity runs) */
+    int32_t terrain_rows, terrain_cols;
+    float terrain_size_x, max_episode_length_s;
+    /* CommandManager: UniformVelocityCommand; has_command = 0: none */
+    int32_t has_command, heading_command;
+    float command_cfg[16];                 /* as imx_velocity_command's cfg15 */
+    float* vel_command_b_d;                /* (N,3) */
+    float* heading_target_d;
+    uint8_t* is_heading_env_d;
+    uint8_t* is_standing_env_d;
+    float* command_time_left_d;
+    int64_t* command_counter_d;
+    float* metric_error_vel_xy_d;
+    float* metric_error_vel_yaw_d;
+    const float* command_uniforms_d;       /* optional (2,N,7) */
+    /* scene.reset(env_ids): ContactSensor.reset (contact_sensor.py:143-165 + sensor_base.py:182-194), ActuatorNetLSTM.reset */
+    float* cs_timestamp_d;                 /* NULL: the scene has no env-owned contact sensor */
+    float* cs_timestamp_last_update_d;
+    uint8_t* cs_is_outdated_d;
+    float* cs_net_forces_w_d;              /* (N,B,3) */
+    float* cs_net_forces_w_history_d;      /* (N,H,B,3) or NULL */
+    float* cs_last_air_time_d;             /* (N,B) or NULL (track_air_time off) */
+    float* cs_current_air_time_d;
+    float* cs_last_contact_time_d;
+    float* cs_current_contact_time_d;
+    int32_t cs_num_bodies, cs_history_length;
+    float* lstm_hidden_d;                  /* (L, N*J, H) sea_hidden_state or NULL */
+    float* lstm_cell_d;
+    int32_t lstm_layers, lstm_hidden_dim;
+    /* per-workgroup partial sums for the step tail's log entries (imx_buffers.ev_part): {error_vel_xy, error_vel_yaw over the reset
+     * envs; terrain levels over all envs; reset count} x ceil(N / 64) */
+    float* ev_part_d;
+} imx_orch_t;
+/* number of floats of ev_part for num_envs */
+size_t imx_orch_part_floats(int64_t num_envs);
+int imx_reset_orchestrate(const imx_orch_t* orch, imx_stream_t stream);
+
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char* imx_version(void);
-/* sizeof of an ABI struct as this library was compiled (which: 0 imx_state_t, 1 imx_buffers_t, 2 imx_head_loss_t, 3 imx_rollout_slot_t, 4 imx_policy_act_t), 0 for an unknown index:
+/* sizeof of an ABI struct as this library was compiled (which: 0 imx_state_t, 1 imx_buffers_t, 2 imx_head_loss_t, 3 imx_rollout_slot_t, 4 imx_policy_act_t, 5 imx_orch_t, 6 imx_event_term_t), 0 for an unknown index:
  * a binding checks its own layout against it at load time. */
 size_t imx_struct_size(int which);
 const char* imx_last_error(void);

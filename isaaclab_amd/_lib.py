@@ -22,6 +22,7 @@ BUFFER_FIELDS = (
     "episode_length_buf", "action", "prev_action", "processed_action", "reward_buf", "episode_sums", "step_reward",
     "term_dones", "terminated", "truncated", "reset_buf", "reset_env_ids", "counters", "log_out", "obs", "scratch", "mod_state",
     "obs_extra1", "obs_extra2", "obs_extra3", "scan_state", "scan_hit_z", "scan_drift_feed", "log_accum",
+    "ev_part", "ev_flags",  # (ev_flags is an int64 carried in a pointer-sized field)
 )
 
 
@@ -51,6 +52,35 @@ class ImxPolicyAct(ctypes.Structure):  # imx_policy_act_t
                 ("plan", c_void_p), ("state", POINTER(ImxState)), ("buf", POINTER(ImxBuffers)), ("pre_clip", ctypes.c_float)]
 
 
+class ImxEventTerm(ctypes.Structure):  # imx_event_term_t
+    _fields_ = [("op", c_int32), ("mode", c_int32), ("is_global_time", c_int32), ("min_step_count_between_reset", c_int32),
+                ("interval_lo", c_float), ("interval_hi", c_float), ("ranges", c_float * 24), ("num_body_ids", c_int32), ("reserved", c_int32)] + [
+        (n, c_void_p) for n in ("body_ids_d", "last_triggered_step_d", "triggered_once_d", "time_left_d", "uniforms_d", "interval_uniforms_d")]
+
+
+ORCH_MAX_TERMS = 8
+
+
+class ImxOrch(ctypes.Structure):  # imx_orch_t
+    _fields_ = ([("num_envs", c_int64), ("num_joints", c_int64), ("num_bodies", c_int64), ("reset_mask_d", c_void_p), ("step_counter_d", c_void_p),
+                 ("seed", c_uint64), ("dt", c_float), ("do_step", c_int32), ("num_terms", c_int32), ("reserved0", c_int32),
+                 ("terms", ImxEventTerm * ORCH_MAX_TERMS)]
+                + [(n, c_void_p) for n in (
+                    "default_root_state_d", "default_joint_pos_d", "default_joint_vel_d", "soft_joint_pos_limits_d", "soft_joint_vel_limits_d",
+                    "root_pos_w_d", "root_quat_w_d", "root_lin_vel_w_d", "root_ang_vel_w_d", "env_origins_d", "root_pose_out_d", "root_vel_out_d",
+                    "joint_pos_out_d", "joint_vel_out_d", "ext_force_out_d", "ext_torque_out_d", "terrain_origins_d", "terrain_types_d",
+                    "terrain_levels_d", "rand_levels_d")]
+                + [("terrain_rows", c_int32), ("terrain_cols", c_int32), ("terrain_size_x", c_float), ("max_episode_length_s", c_float),
+                   ("has_command", c_int32), ("heading_command", c_int32), ("command_cfg", c_float * 16)]
+                + [(n, c_void_p) for n in (
+                    "vel_command_b_d", "heading_target_d", "is_heading_env_d", "is_standing_env_d", "command_time_left_d", "command_counter_d",
+                    "metric_error_vel_xy_d", "metric_error_vel_yaw_d", "command_uniforms_d", "cs_timestamp_d", "cs_timestamp_last_update_d",
+                    "cs_is_outdated_d", "cs_net_forces_w_d", "cs_net_forces_w_history_d", "cs_last_air_time_d", "cs_current_air_time_d",
+                    "cs_last_contact_time_d", "cs_current_contact_time_d")]
+                + [("cs_num_bodies", c_int32), ("cs_history_length", c_int32), ("lstm_hidden_d", c_void_p), ("lstm_cell_d", c_void_p),
+                   ("lstm_layers", c_int32), ("lstm_hidden_dim", c_int32), ("ev_part_d", c_void_p)])
+
+
 class ImxError(RuntimeError):
     pass
 
@@ -72,6 +102,8 @@ _SIGNATURES = {
     "imx_terminations_rewards_rollout": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_int, POINTER(ImxRolloutSlot),
                                                  c_void_p]),
     "imx_observations_kernel_name": (c_char_p, [c_void_p]),
+    "imx_orch_part_floats": (c_size_t, [c_int64]),
+    "imx_reset_orchestrate": (c_int, [POINTER(ImxOrch), c_void_p]),
     "imx_observations": (c_int, [c_void_p, c_int64, POINTER(ImxState), POINTER(ImxBuffers), c_void_p, c_void_p, c_uint64,
                                  c_int, c_void_p, c_void_p]),
     "imx_root_frame": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p,
@@ -164,7 +196,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((ImxState, ImxBuffers, ImxHeadLoss, ImxRolloutSlot, ImxPolicyAct)):  # the binding's struct layouts against the library's
+    for which, cls in enumerate((ImxState, ImxBuffers, ImxHeadLoss, ImxRolloutSlot, ImxPolicyAct, ImxOrch, ImxEventTerm)):  # the binding's struct layouts against the library's
         if int(L.imx_struct_size(which)) != ctypes.sizeof(cls):
             raise ImxError(f"{LIB_PATH}: sizeof({cls.__name__}) is {int(L.imx_struct_size(which))} in the library, {ctypes.sizeof(cls)} in the "
                            "binding -- rebuild with `python -m isaaclab_amd.build`")

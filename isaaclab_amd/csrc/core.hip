@@ -29,6 +29,8 @@ extern "C" size_t imx_struct_size(int which) {
         case 2: return sizeof(imx_head_loss_t);
         case 3: return sizeof(imx_rollout_slot_t);
         case 4: return sizeof(imx_policy_act_t);
+        case 5: return sizeof(imx_orch_t);
+        case 6: return sizeof(imx_event_term_t);
         default: return 0;
     }
 }

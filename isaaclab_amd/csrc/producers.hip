@@ -5,6 +5,7 @@
 //     isaaclab/envs/mdp/commands/velocity_command.py:111-160): metrics, resampling timer, uniform resampling,
 //     heading P-controller (wrap_to_pi), standing envs.
 #include "imx_internal.h"
+#include "imx_producers.h"
 
 // ------------------------------------------------------------------------------------------------- contact sensor
 // lane = (env, body).  SensorBase.update: timestamp += dt; outdated |= timestamp - last_update + 1e-6 >= update_period;
@@ -86,89 +87,16 @@ extern "C" int imx_contact_sensor_update(int64_t N, int64_t B, int64_t H, const 
 }
 
 // ------------------------------------------------------------------------------------------------- velocity command
-// lane = env.  uniforms: (N,7) samples in [0,1) for {time_left, lin_x, lin_y, ang_z, heading, is_heading, is_standing}
-// (parity mode, the reference draws them with Tensor.uniform_ on the CPU generator) or NULL -> counter-based in-kernel.
-struct VelCmdCfg {
-    float resample_lo, resample_hi;
-    float lin_x_lo, lin_x_hi, lin_y_lo, lin_y_hi, ang_z_lo, ang_z_hi, heading_lo, heading_hi;
-    float rel_standing, rel_heading, stiffness;
-    int heading_command;
-    float max_command_step;  // resampling_time_range[1] / step_dt
-};
-
-IMX_DEV float u_at(const float* __restrict__ U, int64_t e, int k, uint64_t seed, uint32_t step) {
-    return U ? U[e * 7 + k] : uniform01(seed + 0x1234567ull * (uint64_t)(k + 1), step, (uint64_t)e);
-}
-
+// lane = env (the per-env logic is velocity_command_env, imx_producers.h: shared with the orchestration kernel)
 __global__ void __launch_bounds__(256)
 k_velocity_command(int64_t N, VelCmdCfg c, float dt, int do_compute, const float* __restrict__ quat, const float* __restrict__ lin_w,
                    const float* __restrict__ ang_w, const uint8_t* __restrict__ reset_mask,
-                   const float* __restrict__ uniforms, uint64_t seed, const int32_t* __restrict__ step_d,
-                   float* __restrict__ cmd, float* __restrict__ heading_target, uint8_t* __restrict__ is_heading,
-                   uint8_t* __restrict__ is_standing, float* __restrict__ time_left, int64_t* __restrict__ counter,
-                   float* __restrict__ metric_xy, float* __restrict__ metric_yaw) {
+                   const float* __restrict__ uniforms, uint64_t seed, const int32_t* __restrict__ step_d, VelCmdState s) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const uint32_t step = step_d ? (uint32_t)step_d[0] : 0u;
-    const float qw = quat[e * 4], qx = quat[e * 4 + 1], qy = quat[e * 4 + 2], qz = quat[e * 4 + 3];
-    float cx = cmd[e * 3], cy = cmd[e * 3 + 1], cz = cmd[e * 3 + 2];
-    float tl = time_left[e];
-    int64_t cnt = counter[e];
-    float mxy = metric_xy[e], myaw = metric_yaw[e];
-    float htgt = heading_target[e];
-    bool head = is_heading[e] != 0, stand = is_standing[e] != 0;
-    bool resample = false;
-    int draw = 0;  // which of the two possible resamplings of this call (reset, timer) -> distinct in-kernel streams
-    if (reset_mask && reset_mask[e]) {  // CommandTerm.reset (command_manager.py:119-147): metrics, counter, resample
-        mxy = 0.0f; myaw = 0.0f; cnt = 0;
-        resample = true;
-    }
-    for (int pass = 0; pass < (do_compute ? 2 : 1); ++pass) {
-        if (pass == 1) {
-            // CommandTerm.compute (:149-166): metrics on the current command, timer, resample when it ran out
-            float lbx, lby, lbz, abx, aby, abz;
-            quat_rotate_inverse(qw, qx, qy, qz, lin_w[e * 3], lin_w[e * 3 + 1], lin_w[e * 3 + 2], lbx, lby, lbz);
-            quat_rotate_inverse(qw, qx, qy, qz, ang_w[e * 3], ang_w[e * 3 + 1], ang_w[e * 3 + 2], abx, aby, abz);
-            const float ex = cx - lbx, ey = cy - lby;
-            mxy += sqrtf(ex * ex + ey * ey) / c.max_command_step;  // velocity_command.py:117-123
-            myaw += fabsf(cz - abz) / c.max_command_step;
-            tl -= dt;
-            resample = tl <= 0.0f;
-        }
-        if (resample) {  // CommandTerm._resample (:172-187) + _resample_command (velocity_command.py:125-140)
-            const float* U = uniforms ? uniforms + (size_t)draw * N * 7 : nullptr;
-            const uint64_t sd = seed + 0x9E3779B97F4A7C15ull * (uint64_t)draw;
-            tl = u_at(U, e, 0, sd, step) * (c.resample_hi - c.resample_lo) + c.resample_lo;
-            cnt += 1;
-            cx = u_at(U, e, 1, sd, step) * (c.lin_x_hi - c.lin_x_lo) + c.lin_x_lo;
-            cy = u_at(U, e, 2, sd, step) * (c.lin_y_hi - c.lin_y_lo) + c.lin_y_lo;
-            cz = u_at(U, e, 3, sd, step) * (c.ang_z_hi - c.ang_z_lo) + c.ang_z_lo;
-            if (c.heading_command) {
-                htgt = u_at(U, e, 4, sd, step) * (c.heading_hi - c.heading_lo) + c.heading_lo;
-                head = u_at(U, e, 5, sd, step) <= c.rel_heading;
-            }
-            stand = u_at(U, e, 6, sd, step) <= c.rel_standing;
-            ++draw;
-        }
-        resample = false;
-    }
-    // _update_command (velocity_command.py:142-160)
-    if (do_compute && c.heading_command && head) {
-        float fx, fy, fz;
-        quat_apply(qw, qx, qy, qz, 1.0f, 0.0f, 0.0f, fx, fy, fz);  // heading_w (articulation_data.py:518-526)
-        const float heading = atan2f(fy, fx);
-        const float err = wrap_to_pi(htgt - heading);
-        cz = fminf(fmaxf(c.stiffness * err, c.ang_z_lo), c.ang_z_hi);
-    }
-    if (do_compute && stand) { cx = 0.0f; cy = 0.0f; cz = 0.0f; }
-    cmd[e * 3] = cx; cmd[e * 3 + 1] = cy; cmd[e * 3 + 2] = cz;
-    heading_target[e] = htgt;
-    is_heading[e] = head ? 1 : 0;
-    is_standing[e] = stand ? 1 : 0;
-    time_left[e] = tl;
-    counter[e] = cnt;
-    metric_xy[e] = mxy;
-    metric_yaw[e] = myaw;
+    float m0, m1;
+    velocity_command_env(N, e, c, dt, do_compute, quat, lin_w, ang_w, reset_mask && reset_mask[e], uniforms, seed, step, s, m0, m1);
 }
 
 extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_command, float dt, int do_compute,
@@ -183,18 +111,12 @@ extern "C" int imx_velocity_command(int64_t N, const float* cfg15, int heading_c
     IMX_REQUIRE(root_quat_w_d && root_lin_vel_w_d && root_ang_vel_w_d && vel_command_b_d && heading_target_d &&
                     is_heading_env_d && is_standing_env_d && time_left_d && command_counter_d && metric_error_vel_xy_d &&
                     metric_error_vel_yaw_d, "imx_velocity_command: null argument");
-    VelCmdCfg c;
-    c.resample_lo = cfg15[0]; c.resample_hi = cfg15[1];
-    c.lin_x_lo = cfg15[2]; c.lin_x_hi = cfg15[3]; c.lin_y_lo = cfg15[4]; c.lin_y_hi = cfg15[5];
-    c.ang_z_lo = cfg15[6]; c.ang_z_hi = cfg15[7]; c.heading_lo = cfg15[8]; c.heading_hi = cfg15[9];
-    c.rel_standing = cfg15[10]; c.rel_heading = cfg15[11]; c.stiffness = cfg15[12];
-    c.max_command_step = cfg15[13];
-    c.heading_command = heading_command;
+    const VelCmdCfg c = vel_cmd_cfg_from15(cfg15, heading_command);
     IMX_REQUIRE(c.max_command_step > 0.0f, "imx_velocity_command: max_command_step must be positive");
+    VelCmdState st{vel_command_b_d, heading_target_d, is_heading_env_d, is_standing_env_d, time_left_d, command_counter_d,
+                   metric_error_vel_xy_d, metric_error_vel_yaw_d};
     hipLaunchKernelGGL(k_velocity_command, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, c, dt,
-                       do_compute, root_quat_w_d, root_lin_vel_w_d, root_ang_vel_w_d, reset_mask_d, uniforms_d, seed, step_counter_d,
-                       vel_command_b_d, heading_target_d, is_heading_env_d, is_standing_env_d, time_left_d,
-                       command_counter_d, metric_error_vel_xy_d, metric_error_vel_yaw_d);
+                       do_compute, root_quat_w_d, root_lin_vel_w_d, root_ang_vel_w_d, reset_mask_d, uniforms_d, seed, step_counter_d, st);
     IMX_HIP(hipGetLastError());
     return 0;
 }

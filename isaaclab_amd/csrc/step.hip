@@ -307,6 +307,28 @@ IMX_DEV void step_tail(const PlanView& P, int64_t N, const imx_buffers_t& Bf, co
         for (int k = first; k < nlog; k += stride)
             if (lane == 0) Bf.log_accum[k] += Bf.log_out[k];
     }
+    // the orchestration's entries (imx_reset_orchestrate ran between the step kernel and this tail): Metrics/<command>/error_vel_xy|yaw =
+    // mean over the reset envs of the metric before its reset (command_manager.py:123-149), Curriculum/terrain_levels = mean level over ALL
+    // envs (curriculums.py:55, curriculum_manager.py:95-118); slots behind the reset count
+    if (Bf.ev_part) {
+        const int ng = (int)((N + 63) / 64);
+        for (int j = first; j < 3; j += stride) {
+            if (!((Bf.ev_flags >> (j < 2 ? 0 : 1)) & 1)) continue;
+            const int slot = nlog + 1 + j;
+            if (total > 0) {
+                float s = 0.0f;
+                for (int w = lane; w < ng; w += 64) s += __builtin_nontemporal_load(&Bf.ev_part[(size_t)w * 4 + j]);
+                s = wave_sum(s);
+                const float v = j < 2 ? s / (float)total : s / (float)N;
+                if (lane == 0) {
+                    Bf.log_out[slot] = v;
+                    if (Bf.log_accum) Bf.log_accum[slot] += v;
+                }
+            } else if (Bf.log_accum && lane == 0) {
+                Bf.log_accum[slot] += Bf.log_out[slot];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- terminations + rewards

@@ -535,7 +535,19 @@ class ManagerBasedRLEnv:
                  robot: RobotSpec | str | None = None, terrain=None, num_envs: int | None = None,
                  device: str | torch.device | None = None, seed: int | None = None, noise_seed: int = 0,
                  terrain_cell: float = 0.0, use_command_term: bool = False, use_contact_sensor: bool = False,
-                 events_cfg: dict | None = None, **kwargs):
+                 events_cfg: dict | bool | None = None, use_curriculum: bool = False, terrain_importer=None, own_managers: bool = False,
+                 **kwargs):
+        """``own_managers=True``: the env runs its cfg's EventManager (reset / interval terms), CommandManager (UniformVelocityCommand)
+        and CurriculumManager (terrain_levels_vel) itself -- ``_reset_idx`` + the command / interval updates of ``step`` as ONE
+        orchestration launch (``imx_reset_orchestrate``) -- instead of taking commands from the feed; the single switches
+        (``events_cfg`` = a dict or True for the cfg's own, ``use_command_term``, ``use_curriculum``) select parts of it.
+        ``terrain_importer``: an ``events.TerrainImporterState`` (default: built from the cfg's terrain generator grid)."""
+        if own_managers:
+            ec = cfg.get("env", cfg) if isinstance(cfg, dict) else None
+            ec = ec if ec is not None else (load_task_cfg(cfg)["env"] if isinstance(cfg, str) else cfg.to_dict())
+            use_command_term = use_command_term or bool(ec.get("commands"))
+            events_cfg = events_cfg if events_cfg is not None else (True if ec.get("events") else None)
+            use_curriculum = use_curriculum or any(v is not None for v in (ec.get("curriculum") or {}).values())
         if isinstance(cfg, str):
             cfg = load_task_cfg(cfg)
         self.cfg = cfg
@@ -611,7 +623,7 @@ class ManagerBasedRLEnv:
         self._reset_env_ids = z(N, dtype=torch.long)
         self._counters = z(8, dtype=torch.int32)
         self.noise_seed = self._noise_seed
-        self._log_out = z(K + NT + 1)
+        self._log_out = z(K + NT + 1 + 3)  # + the orchestration's entries: Metrics/<command>/error_vel_xy|yaw, Curriculum/terrain_levels
         self._obs_groups = [z(N, max(g.dim, 1)) for g in plan.obs_groups]  # one (N, D_g) tensor per observation group
         self._obs = self._obs_groups[0]
         self._ext_reward = z(N, plan.n_ext_rew) if plan.n_ext_rew else None
@@ -677,15 +689,34 @@ class ManagerBasedRLEnv:
             self.contact_sensor = ContactSensorState(N, plan.num_bodies, int(cs.get("history_length", 0)),
                                                      bool(cs.get("track_air_time", False)), float(cs.get("update_period", 0.0)),
                                                      float(cs.get("force_threshold", 1.0)), self.device)
-        # -- optional reset events run by the env on the step kernel's reset mask: what the reference's
-        # EventManager.apply("reset") hands to write_root_pose_to_sim / write_root_velocity_to_sim / write_joint_state_to_sim
-        # lands in ``sim_writes`` (the simulator itself is out of scope; the feed keeps playing its snapshots)
-        self.reset_events = None
+        # -- the reset / interval orchestration: EventManager.apply("reset" | "interval"), the terrain curriculum, the
+        # command term's reset / compute and scene.reset as ONE launch on the step kernel's reset mask.  What the reference hands to
+        # write_root_pose_to_sim / write_root_velocity_to_sim / write_joint_state_to_sim / set_external_force_and_torque lands in
+        # ``sim_writes`` (the simulator itself is out of scope; the feed keeps playing its snapshots)
+        self.event_manager = self.curriculum_manager = self.terrain_importer = None
+        self.actuator_net = None  # an env-owned ActuatorNetLSTM (attach_actuator): its state restarts with the env (scene.reset)
+        self._orch = None
+        J = plan.num_joints
         if events_cfg:
-            from .events import ResetEvents
+            from .events import EventManager
 
-            J = plan.num_joints
-            self.reset_events = ResetEvents.from_cfg(events_cfg, N, J, self.device, seed=noise_seed)
+            ev = env_dict.get("events") if events_cfg is True else events_cfg
+            if not ev:
+                raise ValueError("events_cfg=True but the env cfg has no events")
+            self.event_manager = EventManager(ev, N, plan.robot, self.device, seed=noise_seed)
+        if use_curriculum:
+            from .events import CurriculumManager, TerrainImporterState
+
+            if terrain_importer is None:
+                tg = ((env_dict.get("scene") or {}).get("terrain") or {}).get("terrain_generator")
+                if not tg:
+                    raise ValueError("use_curriculum=True needs a terrain generator grid in the cfg or terrain_importer=")
+                terrain_importer = TerrainImporterState.from_generator_cfg(N, tg, self.device)
+            self.terrain_importer = terrain_importer
+            self.curriculum_manager = CurriculumManager(env_dict.get("curriculum") or {}, self)
+            if self.command_term is None:
+                raise ValueError("the terrain curriculum reads the env's own velocity command: use_command_term=True")
+        if self.event_manager is not None or self.command_term is not None or self.curriculum_manager is not None:
             init = ((env_dict.get("scene") or {}).get("robot") or {}).get("init_state") or {}
             drs = torch.zeros(N, 13, device=self.device)
             drs[:, 0:3] = torch.tensor(init.get("pos", (0.0, 0.0, 0.6)), device=self.device)
@@ -693,8 +724,13 @@ class ManagerBasedRLEnv:
             drs[:, 7:10] = torch.tensor(init.get("lin_vel", (0.0, 0.0, 0.0)), device=self.device)
             drs[:, 10:13] = torch.tensor(init.get("ang_vel", (0.0, 0.0, 0.0)), device=self.device)
             self.default_root_state = drs
+            NB = plan.robot.num_bodies
             self.sim_writes = {"root_pose": torch.zeros(N, 7, device=self.device), "root_vel": torch.zeros(N, 6, device=self.device),
-                               "joint_pos": torch.zeros(N, J, device=self.device), "joint_vel": torch.zeros(N, J, device=self.device)}
+                               "joint_pos": torch.zeros(N, J, device=self.device), "joint_vel": torch.zeros(N, J, device=self.device),
+                               "ext_force": torch.zeros(N, NB, 3, device=self.device), "ext_torque": torch.zeros(N, NB, 3, device=self.device)}
+            self._ev_part = torch.zeros(int(self._lib.imx_orch_part_floats(N)), device=self.device)
+            self._orch_draws = {}  # parity runs: "command" -> (2,N,7) uniforms, "rand_levels" -> (N) int64
+            self.defer_step_tail = True
         self.scene = _Scene(self)
         self._class_terms: list = []  # instances of class-based Python-evaluated terms, in construction order
         self._ext_funcs = {
@@ -704,8 +740,23 @@ class ManagerBasedRLEnv:
         }
         names_r = [t.name for t in plan.reward_terms]
         names_t = [t.name for t in plan.termination_terms]
-        self._log_views = {"Episode_Reward/" + n: self._log_out[i] for i, n in enumerate(names_r)}
-        self._log_views.update({"Episode_Termination/" + n: self._log_out[len(names_r) + i] for i, n in enumerate(names_t)})
+        self._log_index = {"Episode_Reward/" + n: i for i, n in enumerate(names_r)}
+        self._log_index.update({"Episode_Termination/" + n: len(names_r) + i for i, n in enumerate(names_t)})
+        base = len(names_r) + len(names_t) + 1  # (the slot before holds the reset count)
+        ev_flags = 0
+        if self.command_term is not None:  # CommandManager.reset (command_manager.py:340-358): "Metrics/{term}/{metric}"
+            cname = next(iter(env_dict.get("commands") or {"base_velocity": None}))
+            self._log_index[f"Metrics/{cname}/error_vel_xy"] = base
+            self._log_index[f"Metrics/{cname}/error_vel_yaw"] = base + 1
+            ev_flags |= 1
+        if self.curriculum_manager is not None:
+            for n in self.curriculum_manager.active_terms:  # curriculum_manager.py:95-118
+                self._log_index[f"Curriculum/{n}"] = base + 2
+            ev_flags |= 2
+        self._log_views = {k: self._log_out[i] for k, i in self._log_index.items()}
+        if getattr(self, "_ev_part", None) is not None:
+            self._bufs.ev_part = self._ev_part.data_ptr()
+            self._bufs.ev_flags = ev_flags
         self._configure_gym_env_spaces()
         if seed is not None:
             self.seed(seed)
@@ -851,6 +902,8 @@ class ManagerBasedRLEnv:
                 kw["command"] = self.command_term.vel_command_b.data_ptr()
                 kw["command_time_left"] = self.command_term.time_left.data_ptr()
                 kw["command_counter"] = self.command_term.command_counter.data_ptr()
+            if self.terrain_importer is not None:  # scene.env_origins is the importer's tensor (the curriculum moves it)
+                kw["env_origins"] = self.terrain_importer.env_origins.data_ptr()
             if self.contact_sensor is not None:
                 d = self.contact_sensor.data
                 kw.update(net_forces_w_history=d.net_forces_w_history.data_ptr(), last_air_time=d.last_air_time.data_ptr(),
@@ -915,6 +968,79 @@ class ManagerBasedRLEnv:
             | (8 if self.scanner_keep_all_hits else 0) | (16 if finish_step_tail else 0), hits, _lib.current_stream(self.device)))
         return self._obs
 
+    @property
+    def _has_orchestration(self) -> bool:
+        return self.event_manager is not None or self.command_term is not None or self.curriculum_manager is not None
+
+    def attach_actuator(self, actuator_net):
+        """An env-owned ``producers.ActuatorNetLSTM``: its hidden / cell state restarts with the env (scene.reset -> Articulation.reset ->
+        ActuatorNetLSTM.reset, actuators/actuator_net.py:66-70) inside the orchestration launch."""
+        self.actuator_net = actuator_net
+        self._orch = None
+
+    def _build_orch(self):
+        from ._lib import ImxOrch
+
+        f, p = self.feed, _lib.ptr
+        o = ImxOrch(num_envs=self.num_envs, num_joints=self.plan.num_joints, num_bodies=self.plan.robot.num_bodies,
+                    step_counter_d=self._counters[2:3].data_ptr(), dt=float(self.step_dt),
+                    default_root_state_d=p(self.default_root_state), default_joint_pos_d=p(f["default_joint_pos"]),
+                    default_joint_vel_d=p(f["default_joint_vel"]), soft_joint_pos_limits_d=p(f["soft_joint_pos_limits"]),
+                    soft_joint_vel_limits_d=p(f["soft_joint_vel_limits"]),
+                    env_origins_d=p(self.terrain_importer.env_origins if self.terrain_importer is not None else f["env_origins"]),
+                    root_pose_out_d=p(self.sim_writes["root_pose"]), root_vel_out_d=p(self.sim_writes["root_vel"]),
+                    joint_pos_out_d=p(self.sim_writes["joint_pos"]), joint_vel_out_d=p(self.sim_writes["joint_vel"]),
+                    ext_force_out_d=p(self.sim_writes["ext_force"]), ext_torque_out_d=p(self.sim_writes["ext_torque"]),
+                    ev_part_d=p(self._ev_part))
+        if self.event_manager is not None:
+            self.event_manager.fill(o)
+        if self.curriculum_manager is not None and self.curriculum_manager.active_terms:
+            ti = self.terrain_importer
+            o.terrain_origins_d, o.terrain_types_d, o.terrain_levels_d = p(ti.terrain_origins), p(ti.terrain_types), p(ti.terrain_levels)
+            o.terrain_rows, o.terrain_cols = int(ti.terrain_origins.shape[0]), int(ti.terrain_origins.shape[1])
+            o.terrain_size_x, o.max_episode_length_s = float(ti.size_x), float(self.max_episode_length_s)
+        ct = self.command_term
+        if ct is not None:
+            o.has_command, o.heading_command = 1, int(ct.heading_command)
+            for k, v in enumerate(ct._cfg15):
+                o.command_cfg[k] = float(v)
+            o.vel_command_b_d, o.heading_target_d = p(ct.vel_command_b), p(ct.heading_target)
+            o.is_heading_env_d, o.is_standing_env_d = p(ct.is_heading_env), p(ct.is_standing_env)
+            o.command_time_left_d, o.command_counter_d = p(ct.time_left), p(ct.command_counter)
+            o.metric_error_vel_xy_d, o.metric_error_vel_yaw_d = p(ct.metrics["error_vel_xy"]), p(ct.metrics["error_vel_yaw"])
+        cs = self.contact_sensor
+        if cs is not None:
+            d = cs.data
+            o.cs_timestamp_d, o.cs_timestamp_last_update_d, o.cs_is_outdated_d = p(cs._timestamp), p(cs._timestamp_last_update), p(cs._is_outdated)
+            o.cs_net_forces_w_d = p(d.net_forces_w)
+            o.cs_net_forces_w_history_d = p(d.net_forces_w_history) if cs.history_length > 0 else None
+            if cs.cfg.track_air_time:
+                o.cs_last_air_time_d, o.cs_current_air_time_d = p(d.last_air_time), p(d.current_air_time)
+                o.cs_last_contact_time_d, o.cs_current_contact_time_d = p(d.last_contact_time), p(d.current_contact_time)
+            o.cs_num_bodies, o.cs_history_length = cs.num_bodies, cs.history_length
+        an = self.actuator_net
+        if an is not None:
+            o.lstm_hidden_d, o.lstm_cell_d = p(an.sea_hidden_state), p(an.sea_cell_state)
+            o.lstm_layers, o.lstm_hidden_dim = an.num_layers, an.hidden_dim
+        return o
+
+    def _orchestrate(self, reset_mask, do_step: bool):
+        """``_reset_idx`` for the flagged envs (+, inside step(), CommandManager.compute and the interval events): ``imx_reset_orchestrate``."""
+        if self._orch is None:
+            self._orch = self._build_orch()
+        o, f = self._orch, self.feed
+        o.reset_mask_d = _lib.ptr(reset_mask)
+        o.do_step = 1 if do_step else 0
+        o.seed = self.noise_seed
+        o.root_pos_w_d, o.root_quat_w_d = f["root_pos_w"].data_ptr(), f["root_quat_w"].data_ptr()
+        o.root_lin_vel_w_d, o.root_ang_vel_w_d = f["root_lin_vel_w"].data_ptr(), f["root_ang_vel_w"].data_ptr()
+        if self.event_manager is not None:
+            for i, t in enumerate(self.event_manager.terms):  # (parity runs re-point these between steps)
+                o.terms[i].uniforms_d, o.terms[i].interval_uniforms_d = _lib.ptr(t.uniforms), _lib.ptr(t.interval_uniforms)
+        o.command_uniforms_d = _lib.ptr(self._orch_draws.get("command"))
+        o.rand_levels_d = _lib.ptr(self._orch_draws.get("rand_levels"))
+        check(self._lib.imx_reset_orchestrate(ctypes.byref(o), _lib.current_stream(self.device)))
+
     # ---- MDP operations ------------------------------------------------------------------------------------------
     def reset(self, seed: int | None = None, env_ids: Sequence[int] | None = None, options: dict | None = None):
         """ManagerBasedEnv.reset (manager_based_env.py:264-315): reset every env, return (obs_dict, extras)."""
@@ -923,6 +1049,7 @@ class ManagerBasedRLEnv:
         ids = slice(None) if env_ids is None else env_ids
         log = {}
         log.update(self.reward_manager.reset(ids))
+        log.update(self.termination_manager.reset(ids))  # (_reset_idx collects every manager's entries, manager_based_rl_env.py:365-389)
         self.action_manager.reset(ids)
         self._episode_length_buf[ids] = 0
         self.extras["log"] = log
@@ -932,11 +1059,23 @@ class ManagerBasedRLEnv:
         f = self.feed
         if self.contact_sensor is not None:
             self.contact_sensor.reset(None if env_ids is None else env_ids)
-        if self.command_term is not None:  # CommandTerm.reset: resample, no compute (manager_based_rl_env.py:379-380)
-            mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
-            mask[ids] = True
-            self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], mask,
-                                      do_compute=False)
+        if self._has_orchestration:
+            # _reset_idx(env_ids) (manager_based_rl_env.py:347-392): curriculum, scene.reset, reset events, manager resets with their
+            # log entries -- no command compute, no interval events (those belong to step()).  Host-side reductions are fine here
+            mask = None
+            if env_ids is not None:
+                mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+                mask[ids] = True
+            if self.command_term is not None:  # CommandTerm.reset logs the metrics before zeroing them (command_manager.py:123-149)
+                cname = [k for k in self._log_index if k.startswith("Metrics/")][0].split("/")[1]
+                for m in ("error_vel_xy", "error_vel_yaw"):
+                    log[f"Metrics/{cname}/{m}"] = torch.mean(self.command_term.metrics[m][ids])
+            self._orchestrate(mask, do_step=False)
+            if self.curriculum_manager is not None:
+                log.update(self.curriculum_manager.reset(ids))
+            for k, v in log.items():  # the device-side log entries follow (the step tail only refreshes them on steps with resets)
+                if k in self._log_index:
+                    self._log_out[self._log_index[k]] = v
         # ObservationManager.reset -> CircularBuffer.reset: the history windows of the reset envs restart from this observation
         if env_ids is None:
             self._compute_observations(fill_history=True)
@@ -984,15 +1123,10 @@ class ManagerBasedRLEnv:
                 for inst in self._class_terms:
                     if hasattr(inst, "reset"):
                         inst.reset(env_ids=rids)
-        if self.reset_events is not None:  # EventManager.apply(mode="reset", env_ids=reset_env_ids) as one masked launch
-            f, w = self.feed, self.sim_writes
-            self.reset_events.reset(self.reset_buf, self.default_root_state, f["env_origins"], w["root_pose"], w["root_vel"],
-                                    f["default_joint_pos"], f["default_joint_vel"], f["soft_joint_pos_limits"],
-                                    f["soft_joint_vel_limits"], w["joint_pos"], w["joint_vel"])
-        # -- commands: CommandTerm.reset for the reset envs + CommandManager.compute(dt) (one kernel), or from the feed
-        if self.command_term is not None:
-            f = self.feed
-            self.command_term.compute(self.step_dt, f["root_quat_w"], f["root_lin_vel_w"], f["root_ang_vel_w"], self.reset_buf)
+        # -- _reset_idx for the reset envs (curriculum, scene.reset, reset events, command reset + Metrics / Curriculum log sums), then
+        #    CommandManager.compute(dt) and the interval events: one launch, or commands from the feed
+        if self._has_orchestration:
+            self._orchestrate(self.reset_buf, do_step=True)
         # -- observations on the post-reset state (one kernel, ray-cast fused); imx_terminations_rewards left the frame table of
         #    this state snapshot behind (the feed's root state is not rewritten by the reset events: they go to sim_writes)
         self._compute_observations(frame_current=True, finish_step_tail=self.defer_step_tail)

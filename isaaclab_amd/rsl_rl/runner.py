@@ -389,11 +389,11 @@ class OnPolicyRunner:
         iteration_time = self.collection_time + self.learn_time
         fps = int(collection_size / max(iteration_time, 1e-9))
         w = self.writer
-        names = list(getattr(env, "_log_views", {}).keys())
+        index = getattr(env, "_log_index", None) or {k: i for i, k in enumerate(getattr(env, "_log_views", {}))}
         acc = self._log_accum.tolist()
         self._log_accum.zero_()
         ep_string = ""
-        for i, key in enumerate(names):  # mean over the steps of the iteration of infos["log"][key]
+        for key, i in index.items():  # mean over the steps of the iteration of infos["log"][key] (Episode_*, Metrics/*, Curriculum/*)
             value = acc[i] / self.num_steps_per_env
             w.add_scalar(key if "/" in key else "Episode/" + key, value, it)
             ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""

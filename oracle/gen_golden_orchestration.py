@@ -1,0 +1,395 @@
+"""TEST INFRASTRUCTURE (build container only): tests/golden/orchestration.npz + isaaclab_amd/configs/Isaac-Velocity-Flat-Anymal-C-v0-orch.json.
+
+The reset / interval ORCHESTRATION of the reference, run with its REAL classes and its REAL ``_reset_idx``:
+
+    ManagerBasedRLEnv._reset_idx (envs/manager_based_rl_env.py:347-392), called unbound on a duck-typed env that carries the real
+    EventManager (managers/event_manager.py: reset-mode terms with ``min_step_count_between_reset``, interval-mode terms with per-env
+    and global timers), CommandManager + UniformVelocityCommand (metrics, resampling), CurriculumManager + terrain_levels_vel +
+    TerrainImporter.update_env_origins, next to the real Action / Observation / Reward / Termination managers;
+    then ``command_manager.compute(dt)`` and ``event_manager.apply("interval", dt)`` as ManagerBasedRLEnv.step does (:232-236).
+
+PhysX is absent: the asset is a recording fake -- ``write_root_pose_to_sim`` / ``write_root_velocity_to_sim`` /
+``write_joint_state_to_sim`` / ``set_external_force_and_torque`` land in persistent "sim_writes" buffers, ``asset.data`` keeps serving the
+state feed (the next state comes from the next snapshot, as everywhere in this repository).  Every random draw of the terms is served
+from recorded tables (per step: U(0,1) rows per env for each event term, the interval timers, the command term; random terrain levels),
+so the HIP path can be fed the same samples: sample_uniform, torch.rand (EventManager), Tensor.uniform_ (CommandTerm) and
+torch.randint_like (TerrainImporter) are patched to read them.
+"""
+
+from __future__ import annotations
+
+import functools
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import gen_golden as gg  # noqa: E402  (installs the import stubs)
+
+import isaaclab.envs.mdp as mdp  # noqa: E402
+import isaaclab.envs.mdp.events as ref_events  # noqa: E402
+from isaaclab.envs import ManagerBasedRLEnv  # noqa: E402
+from isaaclab.envs.mdp.commands.velocity_command import UniformVelocityCommand  # noqa: E402
+from isaaclab.managers import CommandManager, CurriculumManager, EventManager, SceneEntityCfg  # noqa: E402
+from isaaclab.managers import EventTermCfg as EventTerm  # noqa: E402
+from isaaclab.terrains.terrain_importer import TerrainImporter  # noqa: E402
+from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.agents.rsl_rl_ppo_cfg import AnymalCFlatPPORunnerCfg  # noqa: E402
+from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.rough_env_cfg import AnymalCRoughEnvCfg  # noqa: E402
+
+from isaaclab_amd.robots import ANYMAL_C  # noqa: E402
+from isaaclab_amd.state_feed import DYNAMIC, STATIC, StateFeed  # noqa: E402
+
+TASK = "Isaac-Velocity-Flat-Anymal-C-v0-orch"
+N, STEPS, SEED = 64, 48, 131
+R_LEVELS, C_TYPES = 6, 5
+
+
+def make_cfg():
+    cfg = AnymalCRoughEnvCfg()
+    # no height scanner (the ray-cast is pinned elsewhere): the rough task's managers on a plane, WITH its events, commands, curriculum
+    cfg.scene.height_scanner = None
+    cfg.observations.policy.height_scan = None
+    cfg.observations.policy.enable_corruption = False
+    cfg.scene.num_envs = N
+    # startup events touch PhysX materials / masses: simulator side, out of scope
+    cfg.events.physics_material = None
+    cfg.events.add_base_mass = None
+    # reset events: non-zero wrench on the base, a joint reset that may fire at most every 6 env steps
+    cfg.events.base_external_force_torque.params["force_range"] = (-1.5, 2.0)
+    cfg.events.base_external_force_torque.params["torque_range"] = (-0.3, 0.2)
+    cfg.events.reset_robot_joints.min_step_count_between_reset = 6
+    cfg.events.reset_robot_joints.params["velocity_range"] = (-0.5, 0.5)
+    cfg.events.reset_base.params["pose_range"] = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (0.0, 0.05), "roll": (-0.1, 0.1), "yaw": (-3.14, 3.14)}
+    # interval events: per-env timers that run out every 3..7 steps, and a second push on GLOBAL time (one timer, every env at once)
+    cfg.events.push_robot.interval_range_s = (0.06, 0.14)
+    cfg.events.push_global = EventTerm(func=mdp.push_by_setting_velocity, mode="interval", interval_range_s=(0.09, 0.21), is_global_time=True,
+                                       params={"velocity_range": {"yaw": (-0.3, 0.3), "z": (0.0, 0.2)}})
+    # commands: short resampling times so that timer-driven resampling happens inside the fixture; some standing / heading envs
+    cfg.commands.base_velocity.debug_vis = False
+    cfg.commands.base_velocity.resampling_time_range = (0.1, 0.3)
+    cfg.commands.base_velocity.rel_standing_envs = 0.1
+    cfg.commands.base_velocity.rel_heading_envs = 0.7
+    return cfg
+
+
+class RecordingAsset(gg.FakeArticulation):
+    """write_*_to_sim calls land in persistent buffers (rows of the env_ids given); ``data`` keeps serving the feed."""
+
+    def __init__(self, robot, feed, default_root_state):
+        super().__init__(robot, feed)
+        n, J, B = feed.num_envs, robot.num_joints, robot.num_bodies
+        self.sim_writes = {"root_pose": torch.zeros(n, 7), "root_vel": torch.zeros(n, 6), "joint_pos": torch.zeros(n, J),
+                           "joint_vel": torch.zeros(n, J), "ext_force": torch.zeros(n, B, 3), "ext_torque": torch.zeros(n, B, 3)}
+        self.calls = []
+        data = self.data
+        data.default_root_state = default_root_state
+
+        class _Data(type(data)):
+            heading_w = gg.ArticulationData.heading_w  # (forward axis rotated by root_link_quat_w, articulation_data.py:518-526)
+
+            @property
+            def root_vel_w(d):  # ArticulationData.root_vel_w = cat(lin, ang)
+                return torch.cat([d._feed["root_lin_vel_w"], d._feed["root_ang_vel_w"]], dim=-1)
+
+        data.__class__ = _Data
+        data.FORWARD_VEC_B = torch.tensor((1.0, 0.0, 0.0)).repeat(n, 1)
+
+    def _ids(self, env_ids):
+        return slice(None) if env_ids is None else env_ids
+
+    def write_root_pose_to_sim(self, pose, env_ids=None):
+        self.sim_writes["root_pose"][self._ids(env_ids)] = pose
+        self.calls.append("root_pose")
+
+    def write_root_velocity_to_sim(self, vel, env_ids=None):
+        self.sim_writes["root_vel"][self._ids(env_ids)] = vel
+        self.calls.append("root_vel")
+
+    def write_joint_state_to_sim(self, pos, vel, env_ids=None):
+        self.sim_writes["joint_pos"][self._ids(env_ids)] = pos
+        self.sim_writes["joint_vel"][self._ids(env_ids)] = vel
+        self.calls.append("joints")
+
+    def set_external_force_and_torque(self, forces, torques, env_ids=None, body_ids=None):
+        ids = torch.arange(self.num_instances) if env_ids is None else env_ids
+        bids = list(range(self.num_bodies)) if body_ids is None or isinstance(body_ids, slice) else list(body_ids)
+        for k, b in enumerate(bids):
+            self.sim_writes["ext_force"][ids, b] = forces[:, k]
+            self.sim_writes["ext_torque"][ids, b] = torques[:, k]
+        self.calls.append("ext")
+
+
+def main():
+    torch.manual_seed(SEED)
+    cfg = make_cfg()
+    robot = ANYMAL_C
+    J, B = robot.num_joints, robot.num_bodies
+    gen = torch.Generator().manual_seed(SEED + 1)
+    feed = StateFeed(robot, N, "cpu", seed=SEED, num_snapshots=STEPS + 1)
+    init = cfg.scene.robot.init_state
+    drs = torch.zeros(N, 13)
+    drs[:, 0:3] = torch.tensor(init.pos)
+    drs[:, 3:7] = torch.tensor(init.rot)
+    drs[:, 7:10] = torch.tensor(init.lin_vel)
+    drs[:, 10:13] = torch.tensor(init.ang_vel)
+
+    # ---- tables of uniform samples, one slice per step (index 0 = env.reset(), 1 + t = step t)
+    T1 = STEPS + 1
+    U = {"reset_base": torch.rand(T1, N, 12, generator=gen), "reset_robot_joints": torch.rand(T1, N, 2 * J, generator=gen),
+         "base_external_force_torque": torch.rand(T1, N, 6, generator=gen), "push_robot": torch.rand(T1, N, 6, generator=gen),
+         "push_global": torch.rand(T1, N, 6, generator=gen)}
+    U_int = torch.rand(T1, 2, N, generator=gen)       # interval re-sampling: [step][interval term index][env] (global: env 0)
+    U_int_init = torch.rand(2, N, generator=gen)      # EventManager._prepare_terms: the first time_left of every interval term
+    U_cmd = torch.rand(T1, 2, N, 7, generator=gen)    # CommandTerm._resample: [step][draw 0 = reset / 1 = timer][env][column]
+    randlev = torch.randint(0, R_LEVELS, (T1, N), generator=gen)
+    walk = torch.rand(T1, N, generator=gen) * 9.0     # distance walked from the env origin (thresholds: 4 m; 0.5 |cmd| 20 s)
+    walk_ang = torch.rand(T1, N, generator=gen) * 6.28
+
+    # ---- wrap the event terms: which term / which env ids is the running call drawing for?
+    ctx = {"name": None, "ids": None, "col": 0, "slot": 0}
+
+    def wrap(name, fn):
+        @functools.wraps(fn)
+        def term(env, env_ids, *a, **k):
+            ctx.update(name=name, ids=torch.arange(N) if env_ids is None else torch.as_tensor(env_ids), col=0)
+            try:
+                return fn(env, env_ids, *a, **k)
+            finally:
+                ctx["name"] = None
+        return term
+
+    for name in ("base_external_force_torque", "reset_base", "reset_robot_joints", "push_robot", "push_global"):
+        t = getattr(cfg.events, name)
+        t.func = wrap(name, t.func)
+
+    def fake_sample_uniform(lower, upper, size, device):
+        size = (size,) if isinstance(size, int) else tuple(size)
+        width = int(np.prod(size[1:])) if len(size) > 1 else 1
+        u = U[ctx["name"]][ctx["slot"]][ctx["ids"], ctx["col"]:ctx["col"] + width].reshape(size)
+        ctx["col"] += width
+        return u * (upper - lower) + lower
+
+    real_sample_uniform = ref_events.math_utils.sample_uniform
+    ref_events.math_utils.sample_uniform = fake_sample_uniform
+
+    real_rand = torch.rand
+    init_terms = iter(range(2))
+
+    def fake_rand(*size, **kw):
+        f = sys._getframe(1)
+        if f.f_code.co_name == "_prepare_terms":  # first time_left of an interval term (event_manager.py:_prepare_terms)
+            i = next(init_terms)
+            return U_int_init[i][:size[0]].clone()
+        if f.f_code.co_name == "apply":
+            index = f.f_locals["index"]
+            if f.f_locals["term_cfg"].is_global_time:
+                return U_int[ctx["slot"]][index][:1].clone()
+            return U_int[ctx["slot"]][index][f.f_locals["valid_env_ids"]].clone()
+        return real_rand(*size, **kw)
+
+    real_randint_like = torch.randint_like
+
+    def fake_randint_like(x, *a, **k):
+        f = sys._getframe(1)
+        if f.f_code.co_name == "update_env_origins":
+            return randlev[ctx["slot"]][f.f_locals["env_ids"]].clone()
+        return real_randint_like(x, *a, **k)
+
+    cmd_ctx = {"ids": None, "col": 0, "draw": torch.zeros(N, dtype=torch.long)}
+    real_uniform = torch.Tensor.uniform_
+    real_resample = UniformVelocityCommand._resample
+
+    def fake_uniform(self, lo=0.0, hi=1.0):
+        ids, col = cmd_ctx["ids"], cmd_ctx["col"]
+        cmd_ctx["col"] += 1
+        self.copy_(U_cmd[ctx["slot"]][cmd_ctx["draw"][ids], ids, col] * (hi - lo) + lo)
+        return self
+
+    def wrapped_resample(self, env_ids):
+        env_ids = torch.arange(N)[env_ids] if isinstance(env_ids, slice) else torch.as_tensor(env_ids)
+        if len(env_ids) == 0:
+            return
+        cmd_ctx["ids"], cmd_ctx["col"] = env_ids, 0
+        real_resample(self, env_ids)
+        cmd_ctx["draw"][env_ids] += 1
+
+    torch.rand = fake_rand
+    torch.randint_like = fake_randint_like
+    torch.Tensor.uniform_ = fake_uniform
+    UniformVelocityCommand._resample = wrapped_resample
+    rec: dict[str, np.ndarray] = {}
+
+    def put(name, t):
+        rec[name] = t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    try:
+        # ---- the duck-typed env: real managers over the recording asset
+        env = gg.build_ref_env(cfg, robot, feed)
+        asset = RecordingAsset(robot, feed, drs)
+        env.scene._e["robot"] = asset
+        env.scene.articulations = {"robot": asset}
+        env.scene.reset = lambda env_ids=None: None
+        ti = TerrainImporter.__new__(TerrainImporter)
+        ti.cfg = cfg.scene.terrain
+        gx, gy = torch.meshgrid(torch.arange(R_LEVELS, dtype=torch.float32), torch.arange(C_TYPES, dtype=torch.float32), indexing="ij")
+        ti.terrain_origins = torch.stack([(gx - R_LEVELS / 2) * 8.0, (gy - C_TYPES / 2) * 8.0, 0.1 * gx], dim=-1)
+        ti.max_terrain_level = R_LEVELS
+        ti.terrain_levels = torch.randint(0, R_LEVELS, (N,), generator=gen)
+        ti.terrain_types = torch.randint(0, C_TYPES, (N,), generator=gen)
+        ti.env_origins = ti.terrain_origins[ti.terrain_levels, ti.terrain_types].clone()
+        env.scene.terrain = ti
+        type(env.scene).env_origins = property(lambda s: s.terrain.env_origins, lambda s, v: None)
+        put("terrain/origins", ti.terrain_origins)
+        put("terrain/levels0", ti.terrain_levels)
+        put("terrain/types", ti.terrain_types)
+        env.extras = {}
+        env._sim_step_counter = 0
+        env.recorder_manager = types.SimpleNamespace(reset=lambda env_ids=None: {}, active_terms=[])
+        ctx["slot"] = 0
+        env.command_manager = CommandManager(cfg.commands, env)
+        env.event_manager = EventManager(cfg.events, env)
+        env.curriculum_manager = CurriculumManager(cfg.curriculum, env)
+        # the managers built by build_ref_env hold the fake command manager of the other fixtures: rebuild those that read commands
+        env.reward_manager = gg.RewardManager(cfg.rewards, env)
+        env.observation_manager = gg.ObservationManager(cfg.observations, env)
+        term = env.command_manager.get_term("base_velocity")
+        put("interval/time_left_init", torch.stack([tl.expand(N) if tl.numel() == 1 else tl for tl in env.event_manager._interval_term_time_left]))
+        A = env.action_manager.total_action_dim
+        meta = dict(task=TASK, robot=robot.name, num_envs=N, steps=STEPS, seed=SEED, action_dim=int(A),
+                    obs_dim=int(env.observation_manager.group_obs_dim["policy"][0]), step_dt=env.step_dt,
+                    max_episode_length=env.max_episode_length, max_episode_length_s=env.max_episode_length_s, gravity_dir=feed.gravity_dir,
+                    reward_terms=env.reward_manager.active_terms, termination_terms=env.termination_manager.active_terms,
+                    event_terms=env.event_manager.active_terms, interval_terms=env.event_manager.active_terms["interval"],
+                    terrain=dict(rows=R_LEVELS, cols=C_TYPES, size_x=float(cfg.scene.terrain.terrain_generator.size[0])))
+        for n_ in STATIC:
+            if n_ != "env_origins":
+                put("static/" + n_, feed[n_])
+        put("static/default_root_state", drs)
+        for k_, v in U.items():
+            put("draws/" + k_, v)
+        put("draws/interval", U_int)
+        put("draws/interval_init", U_int_init)
+        put("draws/command", U_cmd)
+        put("draws/rand_levels", randlev)
+
+        def set_walked(slot):  # the robots' positions relative to their CURRENT env origins
+            w, a = walk[slot], walk_ang[slot]
+            pos = ti.env_origins + torch.stack([w * torch.cos(a), w * torch.sin(a), torch.full((N,), 0.55)], dim=-1)
+            feed["root_pos_w"].copy_(pos)
+
+        def snapshot(tag):
+            for n_ in DYNAMIC:
+                if n_ != "command":
+                    put(f"{tag}/in/{n_}", feed[n_])
+            put(f"{tag}/in/env_origins_before", env_origins_before)
+            for k_, v in asset.sim_writes.items():
+                put(f"{tag}/sim_writes/{k_}", v)
+            put(f"{tag}/terrain_levels", ti.terrain_levels)
+            put(f"{tag}/env_origins", ti.env_origins)
+            put(f"{tag}/command", term.vel_command_b)
+            put(f"{tag}/command_time_left", term.time_left)
+            put(f"{tag}/command_counter", term.command_counter)
+            put(f"{tag}/heading_target", term.heading_target)
+            put(f"{tag}/is_heading_env", term.is_heading_env)
+            put(f"{tag}/is_standing_env", term.is_standing_env)
+            put(f"{tag}/metric_error_vel_xy", term.metrics["error_vel_xy"])
+            put(f"{tag}/metric_error_vel_yaw", term.metrics["error_vel_yaw"])
+            em = env.event_manager
+            put(f"{tag}/interval_time_left", torch.stack([tl.expand(N) if tl.numel() == 1 else tl for tl in em._interval_term_time_left]))
+            put(f"{tag}/reset_last_triggered_step", torch.stack(em._reset_term_last_triggered_step_id))
+            put(f"{tag}/reset_triggered_once", torch.stack(em._reset_term_last_triggered_once))
+            rec[f"{tag}/log_json"] = np.array(json.dumps({k: float(v) for k, v in env.extras.get("log", {}).items()}))
+            rec[f"{tag}/calls_json"] = np.array(json.dumps(asset.calls))
+            asset.calls.clear()
+
+        # ---- ManagerBasedEnv.reset (manager_based_env.py:264-315): _reset_idx on every env, then the observations
+        ctx["slot"] = 0
+        cmd_ctx["draw"][:] = 0
+        set_walked(0)
+        env_origins_before = ti.env_origins.clone()
+        ManagerBasedRLEnv._reset_idx(env, torch.arange(N))
+        put("reset/obs", env.observation_manager.compute()["policy"])
+        snapshot("reset")
+        ep = torch.randint(0, env.max_episode_length, (N,), generator=gen)
+        ep[::9] = env.max_episode_length - 1
+        ep[4::13] = env.max_episode_length - 3
+        ep[7::11] = env.max_episode_length - 20
+        env.episode_length_buf[:] = ep
+        put("reset/episode_length_buf", env.episode_length_buf)
+
+        n_resets = n_push = n_global = 0
+        for t in range(STEPS):
+            tag = f"step{t}"
+            ctx["slot"] = 1 + t
+            cmd_ctx["draw"][:] = 0
+            action = torch.randn(N, A, generator=gen).clamp(-3, 3)
+            put(f"{tag}/action", action)
+            # ManagerBasedRLEnv.step (manager_based_rl_env.py:153-242)
+            env.action_manager.process_action(action)
+            feed.advance()
+            set_walked(1 + t)
+            env_origins_before = ti.env_origins.clone()
+            env._sim_step_counter += cfg.decimation
+            env.episode_length_buf += 1
+            env.common_step_counter += 1
+            reset_buf = env.termination_manager.compute()
+            reward = env.reward_manager.compute(dt=env.step_dt)
+            put(f"{tag}/reward", reward)
+            put(f"{tag}/terminated", env.termination_manager.terminated)
+            put(f"{tag}/time_outs", env.termination_manager.time_outs)
+            reset_env_ids = reset_buf.nonzero(as_tuple=False).squeeze(-1)
+            put(f"{tag}/reset_env_ids", reset_env_ids)
+            if len(reset_env_ids) > 0:
+                n_resets += len(reset_env_ids)
+                ManagerBasedRLEnv._reset_idx(env, reset_env_ids)
+            env.command_manager.compute(dt=env.step_dt)
+            tl_before = [x.clone() for x in env.event_manager._interval_term_time_left]
+            env.event_manager.apply(mode="interval", dt=env.step_dt)
+            n_push += int(((tl_before[0] - env.step_dt) < 1e-6).sum())
+            n_global += int(((tl_before[1] - env.step_dt) < 1e-6).sum())
+            put(f"{tag}/obs", env.observation_manager.compute()["policy"])
+            put(f"{tag}/episode_length_buf", env.episode_length_buf)
+            snapshot(tag)
+        meta.update(n_resets=n_resets, n_push=n_push, n_global_push=n_global)
+        print(f"[golden] orchestration: {n_resets} resets, {n_push} per-env pushes, {n_global} global pushes over {STEPS} steps; "
+              f"log keys {sorted(env.extras['log'])}")
+        assert n_resets > 40 and n_push > 100 and n_global >= 3
+    finally:
+        torch.rand = real_rand
+        torch.randint_like = real_randint_like
+        torch.Tensor.uniform_ = real_uniform
+        UniformVelocityCommand._resample = real_resample
+        ref_events.math_utils.sample_uniform = real_sample_uniform
+    rec["meta_json"] = np.array(json.dumps(meta))
+
+    # ---- the cfg in to_dict() form (with events / commands / curriculum), like the other fixtures
+    d = cfg.to_dict()
+    keep = {k: d[k] for k in ("decimation", "episode_length_s", "is_finite_horizon", "observations", "actions", "rewards", "terminations",
+                              "commands", "events", "curriculum", "seed") if k in d}
+    keep["sim"] = {"dt": d["sim"]["dt"], "gravity": d["sim"].get("gravity", (0.0, 0.0, -9.81))}
+    scene = d["scene"]
+    keep["scene"] = {"num_envs": scene["num_envs"], "env_spacing": scene["env_spacing"]}
+    cs = dict(scene["contact_forces"])
+    cs.pop("visualizer_cfg", None)
+    keep["scene"]["contact_forces"] = cs
+    keep["scene"]["robot"] = {"init_state": {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in scene["robot"]["init_state"].items()
+                                             if k in ("pos", "rot", "lin_vel", "ang_vel")}}
+    tg = scene["terrain"]["terrain_generator"]
+    keep["scene"]["terrain"] = {"terrain_type": scene["terrain"]["terrain_type"],
+                                "terrain_generator": {k: tg[k] for k in ("size", "border_width", "num_rows", "num_cols", "horizontal_scale",
+                                                                        "vertical_scale", "slope_threshold")}}
+    out = {"task": TASK, "robot": robot.name, "env": keep, "agent": AnymalCFlatPPORunnerCfg().to_dict()}
+    with open(os.path.join(gg.CONFIGS, TASK + ".json"), "w") as f:
+        json.dump(gg._jsonable(out), f, indent=1, sort_keys=False)
+    np.savez_compressed(os.path.join(gg.GOLDEN, "orchestration.npz"), **rec)
+    print("[golden] orchestration:", len(rec), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -88,3 +88,45 @@ def assert_groups_close(got: dict, g: "Golden", tag: str, tol: float):
 def set_reward_weight(cfg_env: dict, term: str, weight: float):
     """What the reference's ``modify_reward_weight`` curriculum term does to the manager's term cfg (envs/mdp/curriculums.py:20-37)."""
     cfg_env["rewards"][term]["weight"] = weight
+
+
+class OrchGolden:
+    """tests/golden/orchestration.npz (oracle/gen_golden_orchestration.py): the REAL ``_reset_idx`` / EventManager / CommandManager /
+    CurriculumManager over a recording asset, 48 steps; every random draw recorded."""
+
+    TASK = "Isaac-Velocity-Flat-Anymal-C-v0-orch"
+
+    def __init__(self):
+        self.z = np.load(os.path.join(GOLDEN, "orchestration.npz"))
+        self.meta = json.loads(str(self.z["meta_json"]))
+        self.fixture = load_task_cfg(self.TASK)
+        self.robot = ROBOTS[self.fixture["robot"]]
+        self.N, self.steps = self.meta["num_envs"], self.meta["steps"]
+        ev = self.fixture["env"]["events"]
+        self.term_names = [n for n, t in ev.items() if t is not None and t.get("mode") in ("reset", "interval")]
+        self.interval_names = [n for n in self.term_names if ev[n]["mode"] == "interval"]
+        self.reset_names = [n for n in self.term_names if ev[n]["mode"] == "reset"]
+
+    def t(self, key) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(self.z[key]))
+
+    def log(self, tag: str) -> dict:
+        return json.loads(str(self.z[f"{tag}/log_json"]))
+
+    def feed(self, device="cpu") -> StateFeed:
+        snaps = []
+        for tag in ["reset"] + [f"step{k}" for k in range(self.steps)]:
+            d = {n: self.t(f"{tag}/in/{n}") for n in DYNAMIC if f"{tag}/in/{n}" in self.z}
+            d["command"] = torch.zeros(self.N, 3)  # unused: the env owns its command term
+            d.update({n: self.t(f"static/{n}") for n in STATIC if n != "env_origins"})
+            d["env_origins"] = self.t("reset/in/env_origins_before")  # unused as well: scene.env_origins is the terrain importer's
+            snaps.append(d)
+        return StateFeed.from_tensors(self.robot, snaps, device=device, gravity_dir=self.meta["gravity_dir"])
+
+    def draws(self, slot: int) -> dict:
+        """The uniform tables of ``slot`` (0 = env.reset(), 1 + t = step t)."""
+        out = {n: self.t("draws/" + n)[slot] for n in self.term_names}
+        out["interval"] = self.t("draws/interval")[slot]
+        out["command"] = self.t("draws/command")[slot]
+        out["rand_levels"] = self.t("draws/rand_levels")[slot]
+        return out

@@ -64,7 +64,7 @@ def test_header_constants_match_plan_compiler():
     for struct, fields in (("imx_state", _lib.STATE_FIELDS), ("imx_buffers", _lib.BUFFER_FIELDS)):
         body = re.search(rf"typedef struct {struct} \{{(.*?)\}}", HEADER, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        names = re.findall(r"\*\s*([a-z_0-9]+)\s*;", body)
+        names = re.findall(r"[\*\s]([a-z_0-9]+)\s*;", body)  # pointer and scalar members
         assert tuple(names) == tuple(fields), struct
 
 

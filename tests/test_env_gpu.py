@@ -313,7 +313,9 @@ def test_env_owned_command_term_and_contact_sensor():
             assert not bool(tout.any()) and torch.equal(env.command_term.command_counter[~term], counter_before[~term])
     cs = env.contact_sensor
     assert torch.equal(cs.data.net_forces_w_history[:, 0], env.feed["net_forces_w_history"][:, 0])
-    assert float(cs._timestamp.max()) == pytest.approx(3 * env.step_dt, rel=1e-5)
+    # every env timed out at k == 1: _reset_idx -> scene.reset(env_ids) -> ContactSensor.reset zeroed the sensor clocks (contact_sensor.py:143-165),
+    # one more step since
+    assert float(cs._timestamp.max()) == pytest.approx(1 * env.step_dt, rel=1e-5)
     assert torch.isfinite(rew).all()
     env.close()
 
@@ -329,7 +331,11 @@ def test_env_owned_reset_events():
               "reset_robot_joints": {"func": "isaaclab.envs.mdp.events:reset_joints_by_scale", "mode": "reset",
                                      "params": {"position_range": (0.5, 1.5), "velocity_range": (0.0, 0.0)}}}
     env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), events_cfg=events)
-    env.reset()
+    assert env.event_manager.active_terms == {"reset": ["reset_base", "reset_robot_joints"]}
+    env.reset()  # ManagerBasedEnv.reset -> _reset_idx(every env): the reset events run on all of them (manager_based_env.py:264-315)
+    assert bool((env.sim_writes["root_pose"][:, 3:7].norm(dim=-1) > 0.99).all())
+    for v in env.sim_writes.values():
+        v.zero_()
     a = torch.zeros(64, 12, device="cuda:0")
     ever = torch.zeros(64, dtype=torch.bool, device="cuda:0")
     for _ in range(4):
@@ -350,6 +356,128 @@ def test_env_owned_reset_events():
     assert bool(ever.any()) and not bool(ever.all())
     assert bool((env.sim_writes["root_pose"][~ever] == 0).all())
     env.close()
+
+
+def _orch_env(g, **kw):
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from isaaclab_amd.events import TerrainImporterState
+
+    ti = TerrainImporterState(g.t("terrain/origins").cuda(), g.t("terrain/levels0").cuda(), g.t("terrain/types").cuda(), g.meta["terrain"]["size_x"])
+    env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), own_managers=True, terrain_importer=ti, **kw)
+    init = g.t("interval/time_left_init").cuda()
+    for i, n in enumerate(g.interval_names):  # EventManager._prepare_terms drew these: take the fixture's
+        t = env.event_manager.get_term(n)
+        t.time_left.copy_(init[i][:1].repeat(2) if t.is_global_time else init[i])
+    return env
+
+
+def _orch_feed_draws(env, g, slot):
+    d = g.draws(slot)
+    for i, n in enumerate(g.interval_names):
+        env.event_manager.get_term(n).interval_uniforms = d["interval"][i].cuda().contiguous()
+    for n in g.term_names:
+        env.event_manager.get_term(n).uniforms = d[n].cuda().contiguous()
+    env._orch_draws["command"] = d["command"].cuda().contiguous()
+    env._orch_draws["rand_levels"] = d["rand_levels"].cuda().contiguous()
+
+
+def test_reset_and_interval_orchestration_matches_the_real_managers():
+    """env.step() with the env's OWN EventManager / CommandManager / CurriculumManager (``own_managers=True``: one imx_reset_orchestrate
+    launch between the step kernel and the observations) against 48 steps of the REAL ``ManagerBasedRLEnv._reset_idx`` + EventManager
+    (``min_step_count_between_reset``, per-env and global interval timers) + CommandManager + CurriculumManager + terrain_levels_vel,
+    fed the reference's recorded draws: what lands in the simulator writes, trigger state and timers bit-exact, commands / metrics /
+    observations / rewards / log entries (incl. ``Metrics/*`` and ``Curriculum/*``) within 1e-5, terrain levels and origins exact."""
+    from _util import OrchGolden
+
+    g = OrchGolden()
+    N = g.N
+    env = _orch_env(g)
+    assert env.event_manager.active_terms == g.meta["event_terms"]
+    assert env.curriculum_manager.active_terms == ["terrain_levels"] and env.event_manager.skipped_terms == []
+    ev, ct, ti = env.event_manager, env.command_term, env.terrain_importer
+
+    def check(tag, extras):
+        torch.cuda.synchronize()
+        for k, v in env.sim_writes.items():
+            assert_close(v, g.t(f"{tag}/sim_writes/{k}"), FLOAT_TOL, f"{tag} sim_writes[{k}]")
+        assert torch.equal(ti.terrain_levels.cpu(), g.t(f"{tag}/terrain_levels")), f"{tag} terrain levels"
+        assert torch.equal(ti.env_origins.cpu(), g.t(f"{tag}/env_origins")), f"{tag} env origins"
+        for k, a in (("command", ct.vel_command_b), ("command_time_left", ct.time_left), ("heading_target", ct.heading_target),
+                     ("metric_error_vel_xy", ct.metrics["error_vel_xy"]), ("metric_error_vel_yaw", ct.metrics["error_vel_yaw"])):
+            assert_close(a, g.t(f"{tag}/{k}"), FLOAT_TOL, f"{tag} {k}")
+        assert torch.equal(ct.command_counter.cpu(), g.t(f"{tag}/command_counter")), f"{tag} command counter"
+        assert torch.equal(ct.is_standing_env.cpu(), g.t(f"{tag}/is_standing_env")) and torch.equal(ct.is_heading_env.cpu(), g.t(f"{tag}/is_heading_env"))
+        step = int(env._counters[2])
+        tl = torch.stack([(t.time_left[(step + 1) & 1].expand(N) if t.is_global_time else t.time_left) for t in (ev.get_term(n) for n in g.interval_names)])
+        assert_close(tl, g.t(f"{tag}/interval_time_left"), 1e-6, f"{tag} interval timers")
+        assert torch.equal(torch.stack([ev.get_term(n).last_triggered_step for n in g.reset_names]).cpu(), g.t(f"{tag}/reset_last_triggered_step")), tag
+        assert torch.equal(torch.stack([ev.get_term(n).triggered_once for n in g.reset_names]).cpu(), g.t(f"{tag}/reset_triggered_once")), tag
+        for key, v in g.log(tag).items():
+            got = float(extras["log"][key])
+            assert abs(got - v) <= FLOAT_TOL * max(1.0, abs(v)), (tag, key, got, v)
+
+    _orch_feed_draws(env, g, 0)
+    obs, extras = env.reset()
+    assert_close(obs["policy"], g.t("reset/obs"), FLOAT_TOL, "reset obs")
+    check("reset", extras)
+    env.episode_length_buf = g.t("reset/episode_length_buf")
+    seen = set()
+    for k in range(g.steps):
+        tag = f"step{k}"
+        _orch_feed_draws(env, g, k + 1)
+        obs, rew, terminated, time_outs, extras = env.step(g.t(f"{tag}/action").cuda())
+        assert torch.equal(terminated.cpu(), g.t(f"{tag}/terminated")) and torch.equal(time_outs.cpu(), g.t(f"{tag}/time_outs"))
+        assert torch.equal(env.reset_env_ids.cpu(), g.t(f"{tag}/reset_env_ids"))
+        assert torch.equal(env.episode_length_buf.cpu(), g.t(f"{tag}/episode_length_buf"))
+        assert_close(rew, g.t(f"{tag}/reward"), FLOAT_TOL, f"{tag} reward")
+        assert_close(obs["policy"], g.t(f"{tag}/obs"), FLOAT_TOL, f"{tag} obs")
+        check(tag, extras)
+        seen |= set(g.log(tag))
+    assert {"Metrics/base_velocity/error_vel_xy", "Metrics/base_velocity/error_vel_yaw", "Curriculum/terrain_levels"} <= seen
+    env.close()
+
+
+def test_orchestration_in_kernel_draws_and_graph_capture():
+    """Performance mode of the same launch (no recorded draws: the counter-based generator): samples inside the cfg ranges, interval
+    timers re-armed inside [lo, hi], a captured rollout of env steps replays with fresh draws, `seed()` makes runs repeat."""
+    from _util import OrchGolden
+
+    g = OrchGolden()
+    out = []
+    for trial in range(2):
+        env = _orch_env(g, seed=7)
+        env.reset()
+        env.episode_length_buf = g.t("reset/episode_length_buf")
+        a = torch.zeros(g.N, 12, device="cuda:0")
+        S = env.feed.num_snapshots
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            env.step(a)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(7):
+                env.step(a)
+        pushes = []
+        for _ in range(6):
+            gr.replay()
+            pushes.append(env.sim_writes["root_vel"].clone())
+        torch.cuda.synchronize()
+        assert not torch.equal(pushes[-1], pushes[-2])  # fresh draws on every replay (keyed by the device step counter)
+        t = env.event_manager.get_term("push_robot")
+        lo, hi = t.interval_range_s
+        assert float(t.time_left.max()) <= hi + 1e-6 and float(t.time_left.min()) > -env.step_dt
+        c = env.command_term.vel_command_b
+        assert float(c.abs().max()) <= 1.0 + 1e-6
+        jp = env.sim_writes["joint_pos"]
+        lim = env.feed["soft_joint_pos_limits"]
+        assert bool((jp >= lim[..., 0] - 1e-6).all()) and bool((jp <= lim[..., 1] + 1e-6).all())
+        assert int(env.terrain_importer.terrain_levels.min()) >= 0 and int(env.terrain_importer.terrain_levels.max()) < g.meta["terrain"]["rows"]
+        out.append((pushes[-1].clone(), env.terrain_importer.terrain_levels.clone(), c.clone()))
+        env.close()
+    assert all(torch.equal(x, y) for x, y in zip(out[0], out[1])), "same seed, same rollout"
 
 
 @pytest.mark.parametrize("mode", ["fused-eager", "fused-graph", "generic-normalized"])

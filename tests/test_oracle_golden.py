@@ -222,3 +222,56 @@ def test_oracle_matches_reference_kitchen_sink():
         for key, v in g.log(k).items():
             assert abs(out["log"][key] - v) <= 1e-6 * max(1.0, abs(v)), key
     assert stale_seen > 10  # the fixture really exercises skipped sensor updates
+
+
+def test_orchestration_oracle_matches_the_real_reset_idx_and_managers():
+    """oracle/orchestration_oracle.py against 48 steps of the REAL ``ManagerBasedRLEnv._reset_idx`` + EventManager (reset terms with
+    ``min_step_count_between_reset``, per-env and global interval timers) + CommandManager + CurriculumManager / terrain_levels_vel:
+    what the terms write to the simulator, trigger state, timers, commands and metrics, terrain levels / origins, log entries."""
+    from _util import OrchGolden
+    from oracle.orchestration_oracle import OrchestrationOracle
+
+    g = OrchGolden()
+    N, meta = g.N, g.meta
+    orc = OrchestrationOracle(g.fixture["env"], N, g.robot.num_joints, g.robot.body_names, meta["step_dt"], meta["max_episode_length_s"],
+                              g.t("static/default_root_state"), g.t("static/default_joint_pos"), g.t("static/default_joint_vel"),
+                              g.t("static/soft_joint_pos_limits"), g.t("static/soft_joint_vel_limits"), g.t("terrain/origins"),
+                              g.t("terrain/levels0"), g.t("terrain/types"), meta["terrain"]["size_x"], g.t("interval/time_left_init"))
+    assert [n for n, _ in orc.terms] == g.term_names
+
+    def feed(tag):
+        return {k: g.t(f"{tag}/in/{k}") for k in ("root_pos_w", "root_quat_w", "root_lin_vel_w", "root_ang_vel_w")}
+
+    def check(tag):
+        for k, v in orc.sim_writes.items():
+            assert_close(v, g.t(f"{tag}/sim_writes/{k}"), 1e-5, f"{tag} sim_writes[{k}]")
+        assert torch.equal(orc.levels, g.t(f"{tag}/terrain_levels")) and torch.equal(orc.env_origins, g.t(f"{tag}/env_origins")), tag
+        c = orc.cmd
+        for k, a in (("command", c.vel_command_b), ("command_time_left", c.time_left), ("heading_target", c.heading_target),
+                     ("metric_error_vel_xy", c.metrics["error_vel_xy"]), ("metric_error_vel_yaw", c.metrics["error_vel_yaw"])):
+            assert_close(a, g.t(f"{tag}/{k}"), 1e-5, f"{tag} {k}")
+        assert torch.equal(c.command_counter, g.t(f"{tag}/command_counter")) and torch.equal(c.is_standing_env, g.t(f"{tag}/is_standing_env"))
+        tl = torch.stack([orc.time_left[n].expand(N) for n in g.interval_names])
+        assert_close(tl, g.t(f"{tag}/interval_time_left"), 1e-6, f"{tag} interval timers")
+        assert torch.equal(torch.stack([orc.last_triggered[n] for n in g.reset_names]), g.t(f"{tag}/reset_last_triggered_step")), tag
+        assert torch.equal(torch.stack([orc.triggered_once[n] for n in g.reset_names]), g.t(f"{tag}/reset_triggered_once")), tag
+        ref_log = g.log(tag)
+        for k, v in orc.log.items():
+            assert abs(ref_log[k] - v) <= 1e-5 * max(1.0, abs(v)), (tag, k, ref_log[k], v)
+
+    d = g.draws(0)
+    orc.cmd._draw[:] = 0
+    orc.reset_idx(torch.arange(N), feed("reset"), 0, d, d["command"], d["rand_levels"])
+    check("reset")
+    pushes = resets = 0
+    for s in range(g.steps):
+        tag, d = f"step{s}", g.draws(s + 1)
+        ids, f = g.t(f"{tag}/reset_env_ids"), feed(tag)
+        orc.cmd._draw[:] = 0
+        if len(ids) > 0:
+            orc.reset_idx(ids, f, s + 1, d, d["command"], d["rand_levels"])
+            resets += len(ids)
+        fired = orc.step_tail(f, d, d["interval"], d["command"])
+        pushes += sum(len(v) for v in fired.values())
+        check(tag)
+    assert resets == meta["n_resets"] and pushes == meta["n_push"] + meta["n_global_push"] * N  # (a global timer pushes every env at once)
