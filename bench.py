@@ -57,7 +57,17 @@ def obs_kernel_bytes_per_env(plan) -> float:
     return float(reads + mesh + writes)
 
 
-def build_env(task, num_envs, device, seed, snapshots, terrain_tiles, mesh=None):
+def anydrive_like_net(device):
+    """A TorchScript-free stand-in for the ANYdrive 3 network of ANYMAL_C_CFG (isaaclab_assets/robots/anymal.py:45-51 downloads the
+    real file from Nucleus: absent offline): LSTM(2 -> 8, 2 layers) + 8 -> 16 -> 1 softsign head, seeded random weights."""
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(device)  # noqa: E731
+    lstm = [(r(32, 2), r(32, 8), r(32), r(32)), (r(32, 8), r(32, 8), r(32), r(32))]
+    head = [(r(16, 8), r(16)), (r(1, 16), r(1))]
+    return lstm, head
+
+
+def build_env(task, num_envs, device, seed, snapshots, terrain_tiles, mesh=None, full_step=False):
     from isaaclab_amd.env import ManagerBasedRLEnv, load_task_cfg
     from isaaclab_amd.robots import ROBOTS
     from isaaclab_amd.state_feed import StateFeed
@@ -74,7 +84,18 @@ def build_env(task, num_envs, device, seed, snapshots, terrain_tiles, mesh=None)
             v, t, e = make_rough_terrain(terrain_tiles[0], terrain_tiles[1], tile=8.0, horizontal_scale=0.1, border=20.0, seed=0)
             terrain, ext, ntri = (v, t), (e[0] - 1.0, e[1] - 1.0), len(t)
     feed = StateFeed(robot, num_envs, device, seed=seed, num_snapshots=snapshots, extent_xy=ext)
-    env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed)
+    if not full_step:
+        env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed)
+        return fx, env, ntri
+    # --full-step: everything the reference runs in torch around the physics step is the env's own -- command term, contact sensor,
+    # reset / interval events, terrain curriculum (imx_reset_orchestrate), ArticulationData refresh, the learned actuator x decimation
+    from isaaclab_amd.producers import ActuatorNetLSTM
+
+    env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed, own_managers=True, use_contact_sensor=True,
+                            use_articulation_update=True)
+    lstm, head = anydrive_like_net(device)
+    env.attach_actuator(ActuatorNetLSTM(num_envs, robot.num_joints, 80.0, 7.5, 120.0, lstm_layers=lstm, head=head, head_activation="softsign",
+                                        device=device))
     return fx, env, ntri
 
 
@@ -135,9 +156,14 @@ def _events_us(fn, launches, device):
         _blocker[device] = (torch.empty(128 * 1024 * 1024, device=device), torch.empty(128 * 1024 * 1024, device=device))
     src, dst = _blocker[device]
     torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        fn()
+    host_us = (time.perf_counter() - t0) / 8 * 1e6  # what the host needs per call (the launches are asynchronous)
+    torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream(device)
-    for _ in range(max(2, launches // 20)):  # ~0.25 ms each
+    for _ in range(max(2, int(launches * host_us * 1.5 / 200.0) + 1)):  # >= 0.2 ms of copy each: the queue never runs dry
         dst.copy_(src)
     e0.record(st)
     for _ in range(launches):
@@ -283,6 +309,65 @@ def time_step_kernels(env, task, T, launches=200):
     return out
 
 
+def time_producers(env, launches=200):
+    """roofline_producers: the SURVEY 8(f) kernels of the full step, each as back-to-back launches on the next state snapshot, with its
+    algorithmic bytes per env against the 8 TB/s peak."""
+    dev, N, f = env.device, env.num_envs, env.feed
+    J, B = env.plan.num_joints, env.plan.robot.num_bodies
+    out = {}
+
+    def entry(name, us, per_env, **kw):
+        gbs = per_env * N / (us * 1e-6) / 1e9
+        out[name] = {"bytes_per_launch": per_env * N, "avg_launch_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, **kw}
+
+    cs, ar, an = env.contact_sensor, env.articulation, env.actuator_net
+    if cs is not None:
+        H = cs.history_length
+
+        def contact():
+            f.advance()
+            cs.update(f["net_forces_w_history"][:, 0], env.step_dt)
+
+        for _ in range(8):
+            contact()
+        entry("k_contact_update + k_contact_stamp", _events_us(contact, launches, dev), 4.0 * (3 * B + (2 * H - 1) * 3 * B + 8 * B + 4) + 2,
+              what="ContactSensor.update: new forces, history shift, air / contact times (two launches)")
+    if env._has_orchestration:
+        def orch():
+            f.advance()
+            env._orchestrate(env.reset_buf, do_step=True)
+
+        for _ in range(8):
+            orch()
+        entry("k_reset_orchestrate", _events_us(orch, launches, dev), 4.0 * (2 * 9 + 10 + 2 + 3) + 2 * 8 + 4,
+              what="_reset_idx of the reset envs + CommandManager.compute + interval events; bytes: command state read + written (9 f), root "
+                   "state 10 f, timers, origins, level, counter, masks (event bodies touch the firing envs only)")
+    if ar is not None:
+        def artic():
+            f.advance()
+            ar.update(f.physx("root_transforms"), f.physx("root_velocities"), f["joint_vel"], env.step_dt)
+
+        for _ in range(8):
+            artic()
+        entry("k_articulation_update", _events_us(artic, launches, dev), 4.0 * (13 + J + 13 + 2 * J),
+              what="ArticulationData: root state re-laid (XYZW -> WXYZ), joint_acc finite difference")
+    if an is not None:
+        tgt = torch.randn(N, J, device=dev)
+
+        def lstm():
+            f.advance()
+            an.compute(tgt, f["joint_pos"], f["joint_vel"])
+
+        for _ in range(8):
+            lstm()
+        L, Hd = an.num_layers, an.hidden_dim
+        entry("k_actuator_net_lstm", _events_us(lstm, launches, dev), 4.0 * J * (3 + 4 * L * Hd + 2),
+              what=f"ActuatorNetLSTM.compute, one launch per physics substep ({int(env.cfg_decimation)} per env step): per (env, joint) sample the "
+                   f"LSTM({L} x {Hd}) state read + written, targets, efforts",
+              flops_per_launch=2.0 * N * J * (4 * Hd * (2 + Hd) + (L - 1) * 4 * Hd * 2 * Hd + Hd * 16 + 16))
+    return out
+
+
 def cpu_baseline(task, num_envs, T, budget_s=12.0):
     """oracle/ restatement of TerminationManager + RewardManager + ObservationManager (+ action affine) + GAE on
     torch-CPU, same synthetic feed distribution (height-scan hits supplied; no ray-cast on the CPU side)."""
@@ -420,6 +505,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--snapshots", type=int, default=4)
     ap.add_argument("--terrain-tiles", type=int, nargs=2, default=(10, 20))
+    ap.add_argument("--full-step", action="store_true", help="the env owns everything the reference runs in torch around the physics step "
+                    "(command term, contact sensor, reset / interval events, terrain curriculum, ArticulationData refresh, ActuatorNetLSTM x "
+                    "decimation): all of it inside the captured rollout; reported as env_step_path_full + roofline_producers")
     ap.add_argument("--no-graph", action="store_true", help="eager rollout instead of one hipGraph replay per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true", help="skip the 65 536-env launches of the observation kernel (they share "
@@ -463,7 +551,7 @@ def main():
     from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
 
     torch.manual_seed(42 + rank)
-    fx, env, ntri = build_env(args.task, args.num_envs, device, 42 + rank, args.snapshots, tuple(args.terrain_tiles))
+    fx, env, ntri = build_env(args.task, args.num_envs, device, 42 + rank, args.snapshots, tuple(args.terrain_tiles), full_step=args.full_step)
     agent = fx["agent"]
     venv = RslRlVecEnvWrapper(env, clip_actions=agent.get("clip_actions"))
     runner = OnPolicyRunner(venv, agent, log_dir=None, device=str(device), use_graph=not args.no_graph)
@@ -526,6 +614,7 @@ def main():
         "config": {"workload": f"{args.task}, {args.num_envs} envs/GPU, T={T}, 5 epochs x 4 minibatches, "
                                f"terrain {ntri} triangles, {args.snapshots} state snapshots resident in HBM",
                    "parallelism": f"dp{world}", "rollout": "eager" if args.no_graph else "hipGraph",
+                   "full_step": bool(args.full_step),
                    "update": ("hipGraph" if getattr(runner.alg, "_update_g", None) is not None else "eager")
                    + (" (measured eager %.2f ms, graph %.2f ms)" % runner.alg._update_times_ms if hasattr(runner.alg, "_update_times_ms") else ""),
                    "policy_params": runner.alg.bucket.numel,
@@ -539,8 +628,13 @@ def main():
     }
     if rank == 0:
         env_rate, env_step_s = time_env_path(env, T, iters=20)
-        out["env_step_path"] = {"value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
-                                "what": "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
+        out["env_step_path_full" if args.full_step else "env_step_path"] = {
+            "value": env_rate, "unit": "env-steps/s", "us_per_env_step_batch": env_step_s * 1e6,
+            "what": ("imx_action_process + ActuatorNetLSTM x decimation + imx_articulation_update + imx_contact_sensor_update + "
+                     "imx_terminations_rewards + imx_reset_orchestrate + imx_observations per step, imx_gae per 24 steps; no policy")
+            if args.full_step else "imx_action_process + imx_terminations_rewards + imx_observations per step, imx_gae per 24 steps; no policy"}
+        if args.full_step:
+            out["roofline_producers"] = time_producers(env)
         steps = time_step_kernels(env, args.task, T)
         obs_name = env._lib.imx_observations_kernel_name(env._plan_h).decode()
         ko = steps[obs_name]
@@ -584,7 +678,8 @@ def main():
         out["ppo"]["learning_rate"] = runner.alg.learning_rate
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.task, args.num_envs, T, args.cpu_budget)
-            out["env_step_path"]["vs_cpu_baseline"] = env_rate / out["cpu_baseline"]["value"]
+            if "env_step_path" in out:
+                out["env_step_path"]["vs_cpu_baseline"] = env_rate / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

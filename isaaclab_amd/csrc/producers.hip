@@ -458,6 +458,99 @@ k_actuator_net_lstm(int64_t n, ImxNetDesc D, const float* __restrict__ weights, 
     applied[i] = dc_motor_clip(c, vel, saturation, elim[i], vlim[i]);
 }
 
+// The ANYdrive shapes (hidden size 8, one or two LSTM layers, a head of 8 -> 1 or 8 -> D0 -> 1) with everything in REGISTERS: the lane's
+// input / hidden / cell vectors are compile-time sized arrays, every loop is unrolled, and the weights -- the same address for all 64
+// lanes -- arrive through the scalar cache as SGPR operands of the multiply-adds.  No LDS at all: the generic kernel above keeps
+// 3 x 64 x 64 floats of lane vectors + the network in LDS (54 KB per single-wave workgroup = two waves per CU), which made
+// ActuatorNetLSTM.compute 56 us per physics substep at 4096 x 12 samples -- 4 x 56 us per env step against 30 us for the whole
+// post-physics path (profiles/r03_*).  Same accumulation order as the generic kernel (and as torch's LSTM cell: gates i, f, g, o).
+template <int H, int D0>
+__global__ void __launch_bounds__(256)
+k_actuator_net_lstm_reg(int64_t n, int num_lstm, int act, const float* __restrict__ weights, const float* __restrict__ q_des,
+                        const float* __restrict__ q, const float* __restrict__ qd, float* __restrict__ hid, float* __restrict__ cell,
+                        float saturation, const float* __restrict__ elim, const float* __restrict__ vlim, float* __restrict__ computed,
+                        float* __restrict__ applied) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float vel = qd[i];
+    float x[H];  // input of the current layer (layer 0: {position error, velocity})
+    x[0] = q_des[i] - q[i];  // sea_input[:, 0, 0] = pos error, [:, 0, 1] = joint velocity (:77-78)
+    x[1] = vel;
+    const float* __restrict__ w = weights;
+    for (int l = 0; l < num_lstm; ++l) {  // (uniform trip count)
+        const int in_dim = l == 0 ? 2 : H;
+        const float* __restrict__ W_ih = w;
+        const float* __restrict__ W_hh = W_ih + 4 * H * in_dim;
+        const float* __restrict__ b_ih = W_hh + 4 * H * H;
+        const float* __restrict__ b_hh = b_ih + 4 * H;
+        float* hs = hid + ((size_t)l * n + i) * H;   // (num_layers, N*J, H), the reference's layout
+        float* cs = cell + ((size_t)l * n + i) * H;
+        float h[H], c[H], hn[H];
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hs + k), cv = *reinterpret_cast<const float4*>(cs + k);
+            h[k] = hv.x; h[k + 1] = hv.y; h[k + 2] = hv.z; h[k + 3] = hv.w;
+            c[k] = cv.x; c[k + 1] = cv.y; c[k + 2] = cv.z; c[k + 3] = cv.w;
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            float g4[4];
+#pragma unroll
+            for (int gI = 0; gI < 4; ++gI) {
+                const int r = gI * H + k;
+                float a = 0.0f, b = 0.0f;
+                if (l == 0) {
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn) a += W_ih[r * 2 + qn] * x[qn];
+                } else {
+#pragma unroll
+                    for (int qn = 0; qn < H; ++qn) a += W_ih[r * H + qn] * x[qn];
+                }
+#pragma unroll
+                for (int qn = 0; qn < H; ++qn) b += W_hh[r * H + qn] * h[qn];
+                g4[gI] = (a + b_ih[r]) + (b + b_hh[r]);
+            }
+            const float c_new = net_sigmoid(g4[1]) * c[k] + net_sigmoid(g4[0]) * tanhf(g4[2]);
+            hn[k] = net_sigmoid(g4[3]) * tanhf(c_new);
+            c[k] = c_new;
+        }
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            *reinterpret_cast<float4*>(hs + k) = make_float4(hn[k], hn[k + 1], hn[k + 2], hn[k + 3]);
+            *reinterpret_cast<float4*>(cs + k) = make_float4(c[k], c[k + 1], c[k + 2], c[k + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = hn[k];
+        w = b_hh + 4 * H;
+    }
+    // the head: H -> 1 (D0 == 0) or H -> D0 -> 1 with `act` in between
+    float out;
+    if (D0 == 0) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int qn = 0; qn < H; ++qn) acc += w[qn] * x[qn];
+        out = acc + w[H];
+    } else {
+        constexpr int DD = D0 > 0 ? D0 : 1;
+        float y[DD];
+        const float* __restrict__ b0 = w + DD * H;
+#pragma unroll
+        for (int j = 0; j < DD; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int qn = 0; qn < H; ++qn) acc += w[j * H + qn] * x[qn];
+            y[j] = net_act(acc + b0[j], act);
+        }
+        const float* __restrict__ W1 = b0 + DD;
+        float acc = 0.0f;
+#pragma unroll
+        for (int qn = 0; qn < DD; ++qn) acc += W1[qn] * y[qn];
+        out = acc + W1[DD];
+    }
+    computed[i] = out;
+    applied[i] = dc_motor_clip(out, vel, saturation, elim[i], vlim[i]);
+}
+
 // ActuatorNetMLP: the (N, history, J) queues of position error and velocity are rolled by one and topped up (:164-170); the inputs of
 // sample (env, joint) are the entries `input_idx` of both queues, scaled, position block first or second (:172-188).
 __global__ void __launch_bounds__(64)
@@ -527,6 +620,21 @@ extern "C" int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hid
     ImxNetDesc D{};
     if (check_net("imx_actuator_net_lstm", num_lstm, hidden, num_dense, dense_out_h, act, 2, num_weights, D)) return 1;
     const int64_t n = N * J;
+    // the ANYdrive shapes run from registers (k_actuator_net_lstm_reg); anything else through the generic LDS kernel
+    if (hidden == 8 && num_lstm <= 4 && (reinterpret_cast<uintptr_t>(hidden_state_d) & 15) == 0 && (reinterpret_cast<uintptr_t>(cell_state_d) & 15) == 0 &&
+        ((num_dense == 1) || (num_dense == 2 && (dense_out_h[0] == 16 || dense_out_h[0] == 32)))) {
+        const unsigned grid = (unsigned)((n + 255) / 256);
+#define IMX_LSTM_REG(D0)                                                                                                                  \
+    hipLaunchKernelGGL((k_actuator_net_lstm_reg<8, D0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n, num_lstm, act, weights_d,      \
+                       joint_pos_target_d, joint_pos_d, joint_vel_d, hidden_state_d, cell_state_d, saturation_effort, effort_limit_d,   \
+                       velocity_limit_d, computed_effort_d, applied_effort_d)
+        if (num_dense == 1) IMX_LSTM_REG(0);
+        else if (dense_out_h[0] == 16) IMX_LSTM_REG(16);
+        else IMX_LSTM_REG(32);
+#undef IMX_LSTM_REG
+        IMX_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds = (size_t)(((num_weights + 3) & ~3) + 3 * IMX_NET_MAXW * 64) * sizeof(float);
     IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_actuator_net_lstm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_actuator_net_lstm, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, n, D, weights_d,

@@ -40,7 +40,17 @@ def load_task_cfg(task: str) -> dict:
     if not os.path.exists(path):
         raise FileNotFoundError(f"no config fixture for task '{task}' under {_CFG_DIR}")
     with open(path) as f:
-        return json.load(f)
+        fx = json.load(f)
+    side = os.path.join(_CFG_DIR, task + ".managers.json")  # events / curriculum / robot init state of the task, dumped separately
+    if os.path.exists(side):
+        with open(side) as f:
+            extra = json.load(f)
+        env = fx["env"]
+        env.setdefault("events", extra.get("events"))
+        env.setdefault("curriculum", extra.get("curriculum"))
+        for k, v in (extra.get("scene") or {}).items():
+            env["scene"].setdefault(k, v)
+    return fx
 
 
 def _string_to_callable(name: str):
@@ -695,6 +705,11 @@ class ManagerBasedRLEnv:
         # ``sim_writes`` (the simulator itself is out of scope; the feed keeps playing its snapshots)
         self.event_manager = self.curriculum_manager = self.terrain_importer = None
         self.actuator_net = None  # an env-owned ActuatorNetLSTM (attach_actuator): its state restarts with the env (scene.reset)
+        self.articulation = None  # an env-owned producers.ArticulationRootState (use_articulation_update=True)
+        if kwargs.pop("use_articulation_update", False):
+            from .producers import ArticulationRootState
+
+            self.articulation = ArticulationRootState(N, plan.num_joints, self.device)
         self._orch = None
         J = plan.num_joints
         if events_cfg:
@@ -902,6 +917,10 @@ class ManagerBasedRLEnv:
                 kw["command"] = self.command_term.vel_command_b.data_ptr()
                 kw["command_time_left"] = self.command_term.time_left.data_ptr()
                 kw["command_counter"] = self.command_term.command_counter.data_ptr()
+            if self.articulation is not None:  # ArticulationData's own buffers (fixed addresses), filled by imx_articulation_update
+                ar = self.articulation
+                kw.update(root_pos_w=ar.root_pos_w.data_ptr(), root_quat_w=ar.root_quat_w.data_ptr(), root_lin_vel_w=ar.root_lin_vel_w.data_ptr(),
+                          root_ang_vel_w=ar.root_ang_vel_w.data_ptr(), joint_acc=ar.joint_acc.data_ptr())
             if self.terrain_importer is not None:  # scene.env_origins is the importer's tensor (the curriculum moves it)
                 kw["env_origins"] = self.terrain_importer.env_origins.data_ptr()
             if self.contact_sensor is not None:
@@ -1032,8 +1051,10 @@ class ManagerBasedRLEnv:
         o.reset_mask_d = _lib.ptr(reset_mask)
         o.do_step = 1 if do_step else 0
         o.seed = self.noise_seed
-        o.root_pos_w_d, o.root_quat_w_d = f["root_pos_w"].data_ptr(), f["root_quat_w"].data_ptr()
-        o.root_lin_vel_w_d, o.root_ang_vel_w_d = f["root_lin_vel_w"].data_ptr(), f["root_ang_vel_w"].data_ptr()
+        src = self.articulation if self.articulation is not None else None
+        get = (lambda n: getattr(src, n)) if src is not None else (lambda n: f[n])
+        o.root_pos_w_d, o.root_quat_w_d = get("root_pos_w").data_ptr(), get("root_quat_w").data_ptr()
+        o.root_lin_vel_w_d, o.root_ang_vel_w_d = get("root_lin_vel_w").data_ptr(), get("root_ang_vel_w").data_ptr()
         if self.event_manager is not None:
             for i, t in enumerate(self.event_manager.terms):  # (parity runs re-point these between steps)
                 o.terms[i].uniforms_d, o.terms[i].interval_uniforms_d = _lib.ptr(t.uniforms), _lib.ptr(t.interval_uniforms)
@@ -1057,8 +1078,12 @@ class ManagerBasedRLEnv:
             if hasattr(inst, "reset"):
                 inst.reset(env_ids=None if env_ids is None else env_ids)
         f = self.feed
+        if self.articulation is not None:  # ArticulationData of the state the env starts from
+            self.articulation.update(f.physx("root_transforms"), f.physx("root_velocities"), f["joint_vel"], self.step_dt)
         if self.contact_sensor is not None:
             self.contact_sensor.reset(None if env_ids is None else env_ids)
+        if self.actuator_net is not None:
+            self.actuator_net.reset(None if env_ids is None else env_ids)
         if self._has_orchestration:
             # _reset_idx(env_ids) (manager_based_rl_env.py:347-392): curriculum, scene.reset, reset events, manager resets with their
             # log entries -- no command compute, no interval events (those belong to step()).  Host-side reductions are fine here
@@ -1095,9 +1120,20 @@ class ManagerBasedRLEnv:
         """``step()`` from the physics on.  The fused rollout (rsl_rl/runner.py) enters here: its actor kernel has already run the
         sampled action through the action terms (imx_mlp_infer_act), and ``rollout_slot`` (an ``ImxRolloutSlot``) makes the step kernel
         write slot t of the RolloutStorage itself (imx_terminations_rewards_rollout)."""
-        # -- physics (decimation x sim.step) is replaced by the feed moving to its next recorded state
+        # -- physics (decimation x sim.step) is replaced by the feed moving to its next recorded state.  What the reference runs around
+        #    every physics step on the torch side stays: the actuator model before it (scene.write_data_to_sim -> Articulation.
+        #    _apply_actuator_model -> ActuatorNetLSTM.compute, manager_based_rl_env.py:182-196) ...
+        if self.actuator_net is not None:
+            f = self.feed
+            for _ in range(int(self.cfg_decimation)):
+                self.actuator_net.compute(self._processed_action, f["joint_pos"], f["joint_vel"])
         self._sim_step_counter += int(self.cfg_decimation)
         self.feed.advance()
+        if self.articulation is not None:
+            # ... and scene.update(dt) after it: ArticulationData refreshed from the PhysX-layout tensors (root transforms XYZW, root
+            # velocities, dof velocities): imx_articulation_update; the step kernels read ITS root state and joint_acc
+            f = self.feed
+            self.articulation.update(f.physx("root_transforms"), f.physx("root_velocities"), f["joint_vel"], self.step_dt)
         if self.contact_sensor is not None:
             # scene.update -> ContactSensor.update: the feed delivers one force sample per env step (history slot 0)
             self.contact_sensor.update(self.feed["net_forces_w_history"][:, 0], self.step_dt)

@@ -194,6 +194,15 @@ class StateFeed:
         self.index = 0
         return self
 
+    def physx(self, name: str) -> torch.Tensor:
+        """The current snapshot in the layout PhysX tensor views deliver (articulation_data.py:365-380): ``root_transforms`` (N,7) = position +
+        quaternion XYZW, ``root_velocities`` (N,6) = linear + angular.  Built once per feed, resident like the snapshots."""
+        if getattr(self, "_physx", None) is None:
+            q = self._stack["root_quat_w"]
+            self._physx = {"root_transforms": torch.cat([self._stack["root_pos_w"], q[..., 1:4], q[..., 0:1]], dim=-1).contiguous(),
+                           "root_velocities": torch.cat([self._stack["root_lin_vel_w"], self._stack["root_ang_vel_w"]], dim=-1).contiguous()}
+        return self._physx[name][self.index]
+
     def advance(self) -> int:
         self.index = (self.index + 1) % self.num_snapshots
         return self.index

@@ -586,7 +586,7 @@ def test_fused_rollout_storage_is_self_consistent(use_graph):
     assert batch[1] is batch[0] and float(batch[0].abs().sum()) > 0
 
 
-@pytest.mark.parametrize("case", ["flat-64-graph", "flat-64-eager", "rough-4096", "flat-2500-clip"])
+@pytest.mark.parametrize("case", ["flat-64-graph", "flat-64-eager", "rough-4096", "flat-2500-clip", "rough-4096-full-graph"])
 def test_three_launch_rollout_step_equals_the_six_launch_split(case):
     """imx_mlp_infer_act (MLPs + PPO.act + ActionManager.process_action) and imx_terminations_rewards_rollout (+ the wrapper's dones,
     the time-out bootstrap, episode statistics; log sum in the step tail) against the split launches of round 2 (imx_mlp_infer,
@@ -615,7 +615,16 @@ def test_three_launch_rollout_step_equals_the_six_launch_split(case):
             if mesh is not None:
                 ext = (float(np.abs(mesh[0][:, 0]).max()) - 2.0, float(np.abs(mesh[0][:, 1]).max()) - 2.0)
             feed = StateFeed(ROBOTS[g.fixture["robot"]], N, "cuda:0", seed=5, num_snapshots=4, extent_xy=ext)
-            env = ManagerBasedRLEnv(g.fixture, state_feed=feed, terrain=mesh, noise_seed=11)
+            if "full" in case:  # bench.py --full-step: the env owns every producer around the physics step, all inside the rollout
+                from bench import anydrive_like_net
+                from isaaclab_amd.producers import ActuatorNetLSTM
+
+                env = ManagerBasedRLEnv(g.fixture, state_feed=feed, terrain=mesh, noise_seed=11, own_managers=True, use_contact_sensor=True,
+                                        use_articulation_update=True)
+                lstm, head = anydrive_like_net("cuda:0")
+                env.attach_actuator(ActuatorNetLSTM(N, 12, 80.0, 7.5, 120.0, lstm_layers=lstm, head=head, head_activation="softsign"))
+            else:
+                env = ManagerBasedRLEnv(g.fixture, state_feed=feed, terrain=mesh, noise_seed=11)
             agent, T = g.fixture["agent"], 4
         venv = RslRlVecEnvWrapper(env, clip_actions=0.8 if case.endswith("clip") else None)
         runner = OnPolicyRunner(venv, dict(agent, num_steps_per_env=T), log_dir=None, device="cuda:0", use_graph=case.endswith("graph"))
@@ -640,12 +649,18 @@ def test_three_launch_rollout_step_equals_the_six_launch_split(case):
                          cur_rew=runner._cur_reward_sum.clone(), cur_len=runner._cur_episode_length.clone(), last_obs=runner.last_obs.clone(),
                          ep_len=env.episode_length_buf.clone(), reset_ids=env.reset_env_ids.clone(), log_out=env._log_out.clone())
         out[fuse]["ep_stats"], out[fuse]["log_accum"] = runner._ep_stats.clone(), runner._log_accum.clone()
+        if "full" in case:
+            out[fuse].update(sim_root_vel=env.sim_writes["root_vel"].clone(), levels=env.terrain_importer.terrain_levels.clone(),
+                             torque=env.actuator_net.applied_effort.clone(), command=env.command_term.vel_command_b.clone(),
+                             air_time=env.contact_sensor.data.current_air_time.clone(), joint_acc=env.articulation.joint_acc.clone())
         env.close()
     a, b = out[False], out[True]
     for k in a:
         if k in ("ep_stats", "log_accum"):
             continue
         assert torch.equal(a[k], b[k]), f"{k}: fused and split rollouts differ"
+    if "full" in case:
+        assert float(a["sim_root_vel"].abs().sum()) > 0 and torch.isfinite(a["torque"]).all() and float(a["torque"].abs().sum()) > 0
     assert float(a["dones"].sum()) > 0 and float(a["log_accum"].abs().sum()) > 0
     assert torch.equal(a["log_accum"], b["log_accum"]), "per-iteration log sums"
     assert_close(b["ep_stats"], a["ep_stats"], 1e-5, "finished-episode statistics (float atomics: order differs)")
