@@ -627,6 +627,11 @@ int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const fl
 typedef struct imx_reduce_batch imx_reduce_batch_t;
 int imx_reduce_batch_create(imx_reduce_batch_t** out);
 void imx_reduce_batch_destroy(imx_reduce_batch_t* batch);
+/* How many workgroups (one per CU) an imx_mlp_dw / imx_mlp_dw_elu launch may split its samples over; 0 = every CU (the default).  The PPO
+ * update runs actor and critic backward passes on two streams at once: with half the chip each (128) the two launches stop competing for
+ * the same CUs and the split partials (written, then re-read by the reduction) halve.  Returns the previous value.  Scratch sized
+ * (imx_mlp_scratch_bytes) under a budget is valid for any budget <= that one. */
+int imx_mlp_set_dw_cu_budget(int cus);
 int imx_reduce_batch_begin(imx_reduce_batch_t* batch);
 int imx_reduce_batch_flush(imx_reduce_batch_t* batch, imx_stream_t stream);
 

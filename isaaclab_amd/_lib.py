@@ -156,6 +156,7 @@ _SIGNATURES = {
                            + [c_void_p] * 3 + [c_void_p]),
     "imx_mlp_scratch_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "imx_mlp_dw": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "imx_mlp_set_dw_cu_budget": (c_int, [c_int]),
     "imx_reduce_batch_create": (c_int, [POINTER(c_void_p)]),
     "imx_reduce_batch_destroy": (None, [c_void_p]),
     "imx_reduce_batch_begin": (c_int, [c_void_p]),

@@ -341,6 +341,7 @@ struct DwPlan {
 };
 
 int g_num_cu = 0;
+int g_dw_cu_budget = 0;  // imx_mlp_set_dw_cu_budget: workgroups (= CUs) one imx_mlp_dw launch may spread its sample splits over; 0 = all
 
 DwPlan dw_plan(int64_t M, int N, int K) {
     if (g_num_cu == 0) {
@@ -353,7 +354,8 @@ DwPlan dw_plan(int64_t M, int N, int K) {
     p.tn = (N + DW_T - 1) / DW_T;
     p.tk = (K + DW_T - 1) / DW_T;
     const int T = p.tn * p.tk;
-    int64_t S = std::max<int64_t>(1, (int64_t)g_num_cu / T);  // one 8-wave workgroup (80 KB of LDS) per CU
+    const int cus = g_dw_cu_budget > 0 ? std::min(g_dw_cu_budget, g_num_cu) : g_num_cu;
+    int64_t S = std::max<int64_t>(1, (int64_t)cus / T);  // one 8-wave workgroup (80 KB of LDS) per CU
     S = std::min<int64_t>(S, std::max<int64_t>(1, M / (2 * DW_BM)));  // at least two stages per split
     if (S >= 8) S &= ~(int64_t)7;
     p.rps = ((M + S - 1) / S + DW_BM - 1) / DW_BM * DW_BM;
@@ -559,6 +561,12 @@ int head_grid(int64_t M) { return (int)std::min<int64_t>((M + 31) / 32, 256); }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int imx_mlp_set_dw_cu_budget(int cus) {
+    const int old = g_dw_cu_budget;
+    g_dw_cu_budget = cus > 0 ? cus : 0;
+    return old;
+}
 
 extern "C" size_t imx_mlp_scratch_bytes(int64_t M, int out_features, int in_features) {
     if (M <= 0 || out_features <= 0 || in_features <= 0) return 0;

@@ -402,6 +402,8 @@ class PPO:
         self._critic_layers = _mlp_layers(self.policy.critic)
         self._ws: dict = {}
         self._side = None
+        if self.device.type == "cuda" and os.getenv("IMX_DW_CU_BUDGET"):  # experiments (tools/): sample splits of imx_mlp_dw over fewer CUs
+            lib().imx_mlp_set_dw_cu_budget(int(os.environ["IMX_DW_CU_BUDGET"]))
         self.two_streams = bool(two_streams)
         if self.device.type == "cuda":
             # HIP binds a stream to one of a few hardware queues at its FIRST use, round-robin: touch the update's streams
