@@ -550,8 +550,31 @@ def main():
 
     from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
 
-    torch.manual_seed(42 + rank)
+    # ---- self-diagnosis of a multi-rank launch (the first N > 1 hardware run is the driver's): fail loudly on a broken rendezvous
+    def pci_id(i):
+        p = torch.cuda.get_device_properties(i)
+        if hasattr(p, "pci_bus_id"):
+            return "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+        return str(getattr(p, "uuid", i))
+
+    my_gpu = pci_id(dev_index)
+    if world > 1 or force_dist:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks but --gpus is {args.gpus}: start exactly one rank per GPU "
+                             "(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N, or plain python bench.py --gpus N)")
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, my_gpu)
+        if not rehearsal and len(set(ids)) != len(ids):
+            raise SystemExit(f"bench.py: two ranks report the same GPU (PCI ids {ids}): LOCAL_RANK / device visibility is wrong -- every rank would "
+                             "time the same card.  (IMX_REHEARSE_ONE_GPU=1 allows it on purpose: a one-GPU rehearsal over gloo.)")
+    else:
+        ids = [my_gpu]
+
+    torch.manual_seed(42 + rank)  # (scripts/reinforcement_learning/rsl_rl/train.py:118-126: seed + local rank, for diversity across ranks)
+    t_build = time.perf_counter()
     fx, env, ntri = build_env(args.task, args.num_envs, device, 42 + rank, args.snapshots, tuple(args.terrain_tiles), full_step=args.full_step)
+    torch.cuda.synchronize(device)
+    terrain_build_s = time.perf_counter() - t_build  # terrain generation + mesh / grid build + state feed + env buffers, per rank
     agent = fx["agent"]
     venv = RslRlVecEnvWrapper(env, clip_actions=agent.get("clip_actions"))
     runner = OnPolicyRunner(venv, agent, log_dir=None, device=str(device), use_graph=not args.no_graph)
@@ -569,10 +592,15 @@ def main():
 
     # untimed priming, whatever --warmup says: the rollout graph is captured in the first iteration and the update decides between
     # eager issue and hipGraph replay over its first five calls (PPO.update) -- neither may fall into the timed region
-    for _ in range(5):
+    t_cap = time.perf_counter()
+    iteration()  # the first one warms up and captures the rollout graph
+    torch.cuda.synchronize(device)
+    graph_capture_s = time.perf_counter() - t_cap
+    for _ in range(4):
         iteration()
     for _ in range(args.warmup):
         iteration()
+    runner.alg.time_allreduce = world > 1 or force_dist
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -591,6 +619,12 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     rank_ms = [1e3 * elapsed / args.steps]
+    ar = runner.alg.allreduce_us()
+    per_rank = {"terrain_build_s": [terrain_build_s], "graph_capture_s": [graph_capture_s], "allreduce_us_mean": [ar["mean"] if ar else None]}
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, (terrain_build_s, graph_capture_s, ar["mean"] if ar else None))
+        per_rank = {"terrain_build_s": [r[0] for r in rows], "graph_capture_s": [r[1] for r in rows], "allreduce_us_mean": [r[2] for r in rows]}
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         every = [torch.zeros_like(tt) for _ in range(world)]
@@ -622,7 +656,9 @@ def main():
                                 "reference's recorded uniforms through the same kernel)"},
         "phase_ms": {"collect_plus_gae": collect_ms, "update": update_ms},
         "ms_per_step_per_rank": rank_ms,
-        "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "distinct_gpus": 1 if rehearsal else world,
+        "per_rank": per_rank,
+        "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "distinct_gpus": len(set(ids)), "gpu_pci_ids": ids,
+                        "allreduce_us": ar,  # rank 0: HIP events around each bucket all-reduce on the update's stream (incl. waiting for peers)
                         "grad_allreduce_per_iteration": int(runner.alg.num_learning_epochs) * int(runner.alg.num_mini_batches),
                         "bucket_bytes": 4 * (runner.alg.bucket.numel + 8)} if (world > 1 or force_dist) else None),
     }

@@ -523,9 +523,28 @@ class PPO:
     def broadcast_parameters(self):
         dist.broadcast(self.bucket.flat, src=0)
 
+    time_allreduce = False  # bench.py: HIP events around every bucket all-reduce (device time on the update's stream, incl. the wait for peers)
+    _allreduce_events: list = []
+
     def reduce_parameters(self):
         """Mean of the flat gradient bucket (+ KL slot) over ranks: ONE all-reduce."""
+        if self.time_allreduce and self.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            allreduce_mean_(self.bucket.grad, self.gpu_world_size)
+            e1.record()
+            self._allreduce_events.append((e0, e1))
+            return
         allreduce_mean_(self.bucket.grad, self.gpu_world_size)
+
+    def allreduce_us(self) -> dict | None:
+        """Mean / max device time of the timed bucket all-reduces (None when none was timed); clears the record."""
+        ev, self._allreduce_events = self._allreduce_events, []
+        if not ev:
+            return None
+        ev[-1][1].synchronize()
+        t = [a.elapsed_time(b) * 1e3 for a, b in ev]
+        return {"mean": sum(t) / len(t), "max": max(t), "count": len(t)}
 
     # ---- update ----------------------------------------------------------------------------------------------------
     def _side_stream(self):

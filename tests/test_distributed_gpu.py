@@ -94,5 +94,23 @@ def test_bench_two_rank_rehearsal():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and len(out["ms_per_step_per_rank"]) == 2
-    assert out["collective"]["ranks"] == 2 and out["collective"]["backend"] == "gloo" and out["collective"]["distinct_gpus"] == 1
+    c = out["collective"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["distinct_gpus"] == 1 and len(c["gpu_pci_ids"]) == 2
+    # the self-diagnosis fields: all-reduce time from HIP events (2 steps x 5 epochs x 4 minibatches), per-rank set-up times
+    assert c["allreduce_us"]["count"] == 2 * c["grad_allreduce_per_iteration"] and c["allreduce_us"]["mean"] > 0
+    pr = out["per_rank"]
+    assert all(len(pr[k]) == 2 for k in ("terrain_build_s", "graph_capture_s", "allreduce_us_mean")) and min(pr["graph_capture_s"]) > 0
     assert out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_rank_count_that_does_not_match_gpus():
+    """A launcher that started a different number of ranks than --gpus says must end in a clear non-zero exit, not a hang or a wrong line."""
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--num-envs", "256",
+                        "--no-cpu-baseline", "--no-large-n"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
