@@ -984,6 +984,10 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
     }
     const float* __restrict__ es = frame + e * IMX_ES_WORDS;  // wave-uniform address
     if (role < waves_per_env - 1) {
+        // the ray's local start depends on the lane only: requested before the first answer of the frame row is looked at (one round
+        // trip of the wave's life less: frame row and ray table travel together)
+        const int j0 = role * 64 + (int)threadIdx.x;
+        const float3 l3_early = reinterpret_cast<const float3*>(W + P.ray_off)[j0 < P.R ? j0 : P.R - 1];
         // height_scan (observations.py:165-173): sensor.data.pos_w z - hit z - offset, then noise -> clip -> scale (observation_manager.py:313-318)
         const int sflags = (int)es[20];
         const bool cast = (sflags & 1) != 0, cache_z = P.scan_stateful && ((sflags & 2) || keep_all_hits);
@@ -1003,7 +1007,7 @@ k_obs_lean(PlanView P, int64_t N, imx_state_t S, imx_buffers_t Bf, MeshView M, c
         float hz = 0.0f;
         if (cast && !GENERAL_RAYS) {
             // RayCaster._update_buffers_impl (ray_caster.py:242-260), yaw-aligned sensor, vertical rays: start = yaw(q) * local + sensor pos
-            const float3 l3 = reinterpret_cast<const float3*>(ray_local)[has ? j : P.R - 1];
+            const float3 l3 = l3_early;
             float sx, sy, sz, t = 0.0f;
             quat_apply_yaw_only(yw, yz, l3.x, l3.y, l3.z, sx, sy, sz);
             sx += px; sy += py; sz += pz;
