@@ -66,29 +66,35 @@ __global__ void __launch_bounds__(ORCH_BLOCK) k_reset_orchestrate(imx_orch_t o) 
         level_f = live ? (float)lv : 0.0f;
     }
 
-    // ---- scene.reset(env_ids): the env-owned sensors / actuators of a reset env start over
-    if (reset && o.cs_timestamp_d) {  // ContactSensor.reset (contact_sensor.py:143-165) + SensorBase.reset (sensor_base.py:182-194)
-        const int B = o.cs_num_bodies, H = o.cs_history_length;
-        o.cs_timestamp_d[e] = 0.0f;
-        o.cs_timestamp_last_update_d[e] = 0.0f;
-        o.cs_is_outdated_d[e] = 1;
-        for (int i = 0; i < B * 3; ++i) o.cs_net_forces_w_d[(size_t)e * B * 3 + i] = 0.0f;
-        if (o.cs_net_forces_w_history_d)
-            for (int i = 0; i < H * B * 3; ++i) o.cs_net_forces_w_history_d[(size_t)e * H * B * 3 + i] = 0.0f;
-        if (o.cs_last_air_time_d)
-            for (int b = 0; b < B; ++b) {
-                o.cs_last_air_time_d[(size_t)e * B + b] = 0.0f; o.cs_current_air_time_d[(size_t)e * B + b] = 0.0f;
-                o.cs_last_contact_time_d[(size_t)e * B + b] = 0.0f; o.cs_current_contact_time_d[(size_t)e * B + b] = 0.0f;
+    // ---- scene.reset(env_ids): the env-owned sensors / actuators of a reset env start over.  The WAVE zeroes the rows of each of its
+    //      reset envs together (lanes stride over the row: coalesced stores, ~10 instructions per env) -- one lane walking its own env's
+    //      272 + 384 floats was 650 store instructions in a divergent branch that 7 of 10 waves enter (25 us for the kernel).
+    const uint64_t reset_lanes = __ballot(reset);
+    if (o.cs_timestamp_d || o.lstm_hidden_d) {
+        for (uint64_t m = reset_lanes; m != 0ull; m &= m - 1ull) {
+            const int64_t er = (int64_t)blockIdx.x * ORCH_BLOCK + (__ffsll((long long)m) - 1);  // wave-uniform
+            if (o.cs_timestamp_d) {  // ContactSensor.reset (contact_sensor.py:143-165) + SensorBase.reset (sensor_base.py:182-194)
+                const int B = o.cs_num_bodies, H = o.cs_history_length;
+                if (lane == 0) { o.cs_timestamp_d[er] = 0.0f; o.cs_timestamp_last_update_d[er] = 0.0f; o.cs_is_outdated_d[er] = 1; }
+                for (int i = lane; i < B * 3; i += ORCH_BLOCK) o.cs_net_forces_w_d[(size_t)er * B * 3 + i] = 0.0f;
+                if (o.cs_net_forces_w_history_d)
+                    for (int i = lane; i < H * B * 3; i += ORCH_BLOCK) o.cs_net_forces_w_history_d[(size_t)er * H * B * 3 + i] = 0.0f;
+                if (o.cs_last_air_time_d)
+                    for (int b = lane; b < B; b += ORCH_BLOCK) {
+                        o.cs_last_air_time_d[(size_t)er * B + b] = 0.0f; o.cs_current_air_time_d[(size_t)er * B + b] = 0.0f;
+                        o.cs_last_contact_time_d[(size_t)er * B + b] = 0.0f; o.cs_current_contact_time_d[(size_t)er * B + b] = 0.0f;
+                    }
             }
-    }
-    if (reset && o.lstm_hidden_d) {  // ActuatorNetLSTM.reset (actuators/actuator_net.py:66-70): hidden / cell state of the env's joints
-        const int Hd = o.lstm_hidden_dim;
-        for (int l = 0; l < o.lstm_layers; ++l)
-            for (int i = 0; i < J * Hd; ++i) {
-                const size_t at = ((size_t)l * N * J + (size_t)e * J) * Hd + i;
-                o.lstm_hidden_d[at] = 0.0f;
-                o.lstm_cell_d[at] = 0.0f;
+            if (o.lstm_hidden_d) {  // ActuatorNetLSTM.reset (actuators/actuator_net.py:66-70): hidden / cell state of the env's joints
+                const int Hd = o.lstm_hidden_dim;
+                for (int l = 0; l < o.lstm_layers; ++l)
+                    for (int i = lane; i < J * Hd; i += ORCH_BLOCK) {
+                        const size_t at = ((size_t)l * N * J + (size_t)er * J) * Hd + i;
+                        o.lstm_hidden_d[at] = 0.0f;
+                        o.lstm_cell_d[at] = 0.0f;
+                    }
             }
+        }
     }
 
     // ---- EventManager.apply("reset", env_ids, global_env_step_count) (event_manager.py:233-260), terms in cfg order
@@ -110,8 +116,28 @@ __global__ void __launch_bounds__(ORCH_BLOCK) k_reset_orchestrate(imx_orch_t o) 
                 }
             }
         }
-        if (!valid) continue;
         const float* __restrict__ U = T.uniforms_d;
+        if (T.op == IMX_E_RESET_JOINTS_BY_SCALE || T.op == IMX_E_RESET_JOINTS_BY_OFFSET) {  // events.py:987-1049
+            // lane = joint of one valid env at a time (the same draws, keyed by (env, column)): 2 J samples + clamps per env spread over
+            // the wave instead of a J-trip loop on the env's own lane
+            const bool by_offset = T.op == IMX_E_RESET_JOINTS_BY_OFFSET;
+            for (uint64_t m = __ballot(valid); m != 0ull; m &= m - 1ull) {
+                const int64_t er = (int64_t)blockIdx.x * ORCH_BLOCK + (__ffsll((long long)m) - 1);  // wave-uniform
+                for (int j = lane; j < J; j += ORCH_BLOCK) {
+                    const size_t q = (size_t)er * J + j;
+                    const float sp = draw(U, 2 * (int64_t)J, er, j, o.seed, t, step) * (T.ranges[1] - T.ranges[0]) + T.ranges[0];
+                    const float sv = draw(U, 2 * (int64_t)J, er, J + j, o.seed, t, step) * (T.ranges[3] - T.ranges[2]) + T.ranges[2];
+                    float p = by_offset ? o.default_joint_pos_d[q] + sp : o.default_joint_pos_d[q] * sp;
+                    float v = by_offset ? o.default_joint_vel_d[q] + sv : o.default_joint_vel_d[q] * sv;
+                    p = fminf(fmaxf(p, o.soft_joint_pos_limits_d[2 * q]), o.soft_joint_pos_limits_d[2 * q + 1]);  // clamp_(lo, hi)
+                    v = fminf(fmaxf(v, -o.soft_joint_vel_limits_d[q]), o.soft_joint_vel_limits_d[q]);
+                    o.joint_pos_out_d[q] = p;
+                    o.joint_vel_out_d[q] = v;
+                }
+            }
+            continue;
+        }
+        if (!valid) continue;
         switch (T.op) {
             case IMX_E_RESET_ROOT_STATE_UNIFORM: {  // events.py:823-868
                 const float* d = o.default_root_state_d + e * 13;
@@ -141,20 +167,7 @@ __global__ void __launch_bounds__(ORCH_BLOCK) k_reset_orchestrate(imx_orch_t o) 
                         d[7 + k] + (draw(U, 12, e, 6 + k, o.seed, t, step) * (T.ranges[12 + 2 * k + 1] - T.ranges[12 + 2 * k]) + T.ranges[12 + 2 * k]);
             } break;
             case IMX_E_RESET_JOINTS_BY_SCALE:
-            case IMX_E_RESET_JOINTS_BY_OFFSET: {  // events.py:987-1049
-                const bool by_offset = T.op == IMX_E_RESET_JOINTS_BY_OFFSET;
-                for (int j = 0; j < J; ++j) {
-                    const size_t q = (size_t)e * J + j;
-                    const float sp = draw(U, 2 * (int64_t)J, e, j, o.seed, t, step) * (T.ranges[1] - T.ranges[0]) + T.ranges[0];
-                    const float sv = draw(U, 2 * (int64_t)J, e, J + j, o.seed, t, step) * (T.ranges[3] - T.ranges[2]) + T.ranges[2];
-                    float p = by_offset ? o.default_joint_pos_d[q] + sp : o.default_joint_pos_d[q] * sp;
-                    float v = by_offset ? o.default_joint_vel_d[q] + sv : o.default_joint_vel_d[q] * sv;
-                    p = fminf(fmaxf(p, o.soft_joint_pos_limits_d[2 * q]), o.soft_joint_pos_limits_d[2 * q + 1]);  // clamp_(lo, hi)
-                    v = fminf(fmaxf(v, -o.soft_joint_vel_limits_d[q]), o.soft_joint_vel_limits_d[q]);
-                    o.joint_pos_out_d[q] = p;
-                    o.joint_vel_out_d[q] = v;
-                }
-            } break;
+            case IMX_E_RESET_JOINTS_BY_OFFSET: break;  // (worked off by the whole wave, below)
             case IMX_E_APPLY_EXTERNAL_FORCE_TORQUE: {  // events.py:764-791: two sample_uniform calls (forces, then torques) of (k, nb, 3)
                 const int nb = T.body_ids_d ? T.num_body_ids : NB;
                 for (int b = 0; b < nb; ++b) {

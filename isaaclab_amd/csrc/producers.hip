@@ -551,6 +551,97 @@ k_actuator_net_lstm_reg(int64_t n, int num_lstm, int act, const float* __restric
     applied[i] = dc_motor_clip(out, vel, saturation, elim[i], vlim[i]);
 }
 
+// The same shapes with EIGHT lanes per sample, lane k = hidden unit k: a lane computes the four gates of ITS unit (4 x (in + 8)
+// multiply-adds + 5 transcendentals per layer) and the group shares the new hidden vector through lane shuffles (ds_bpermute: no LDS
+// allocation, no barrier).  One lane carrying a whole sample (k_actuator_net_lstm_reg) is ~5000 dependent instructions on 768 waves --
+// less than one wave per SIMD, nothing to hide a stall behind: 22 us; eight lanes per sample are ~600 instructions on 6144 waves.
+// State loads / stores become perfectly coalesced (lane = consecutive float of the (num_layers, N*J, 8) tensors).  The weights sit in
+// LDS (4.4 KB, lanes of a group read 8 different rows).  Same per-gate accumulation order as the other two kernels; the head's final
+// sum over the group is a fixed-shape shuffle tree instead of a left-to-right loop (<= 1e-7 relative; tests: 1e-5 against torch).
+template <int D0>
+__global__ void __launch_bounds__(256)
+k_actuator_net_lstm_lanes(int64_t n, int num_lstm, int act, int num_weights, const float* __restrict__ weights, const float* __restrict__ q_des,
+                          const float* __restrict__ q, const float* __restrict__ qd, float* __restrict__ hid, float* __restrict__ cell,
+                          float saturation, const float* __restrict__ elim, const float* __restrict__ vlim, float* __restrict__ computed,
+                          float* __restrict__ applied) {
+    constexpr int H = 8;
+    extern __shared__ float s_w[];
+    for (int k = threadIdx.x; k < num_weights; k += blockDim.x) s_w[k] = weights[k];
+    __syncthreads();
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = gid >> 3;            // sample = (env, joint)
+    const int k = (int)(gid & 7);           // hidden unit of this lane
+    const bool live = i0 < n;
+    const int64_t i = live ? i0 : n - 1;    // (whole groups are live or dead: n x 8 lanes, 8 | 64)
+    const int lane = threadIdx.x & 63, base = lane & ~7;
+    const float vel = qd[i];
+    float x[H];
+    x[0] = q_des[i] - q[i];
+    x[1] = vel;
+    const float* __restrict__ w = s_w;
+    for (int l = 0; l < num_lstm; ++l) {  // (uniform)
+        const int in_dim = l == 0 ? 2 : H;
+        const float* __restrict__ W_ih = w;
+        const float* __restrict__ W_hh = W_ih + 4 * H * in_dim;
+        const float* __restrict__ b_ih = W_hh + 4 * H * H;
+        const float* __restrict__ b_hh = b_ih + 4 * H;
+        const size_t at = ((size_t)l * n + i) * H + k;
+        const float h_own = hid[at], c_own = cell[at];
+        float h[H];
+#pragma unroll
+        for (int qn = 0; qn < H; ++qn) h[qn] = __shfl(h_own, base + qn, 64);
+        float g4[4];
+#pragma unroll
+        for (int gI = 0; gI < 4; ++gI) {
+            const int r = gI * H + k;
+            float a = 0.0f, b = 0.0f;
+            if (l == 0) {
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn) a += W_ih[r * 2 + qn] * x[qn];
+            } else {
+#pragma unroll
+                for (int qn = 0; qn < H; ++qn) a += W_ih[r * H + qn] * x[qn];
+            }
+#pragma unroll
+            for (int qn = 0; qn < H; ++qn) b += W_hh[r * H + qn] * h[qn];
+            g4[gI] = (a + b_ih[r]) + (b + b_hh[r]);
+        }
+        const float c_new = net_sigmoid(g4[1]) * c_own + net_sigmoid(g4[0]) * tanhf(g4[2]);
+        const float h_new = net_sigmoid(g4[3]) * tanhf(c_new);
+        if (live) { cell[at] = c_new; hid[at] = h_new; }
+#pragma unroll
+        for (int qn = 0; qn < H; ++qn) x[qn] = __shfl(h_new, base + qn, 64);
+        w = b_hh + 4 * H;
+    }
+    // the head: H -> 1 (D0 == 0) or H -> D0 -> 1; lane k takes the k-th share of the sum
+    float part;
+    if (D0 == 0) {
+        part = w[k] * x[k];
+    } else {
+        constexpr int DD = D0 > 0 ? D0 : 8;
+        const float* __restrict__ b0 = w + DD * H;
+        const float* __restrict__ W1 = b0 + DD;
+        part = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < DD / H; ++jj) {  // outputs k, k + 8, ...
+            const int j = k + H * jj;
+            float acc = 0.0f;
+#pragma unroll
+            for (int qn = 0; qn < H; ++qn) acc += w[j * H + qn] * x[qn];
+            part += W1[j] * net_act(acc + b0[j], act);
+        }
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    const float bias_out = D0 == 0 ? w[H] : (w + (D0 > 0 ? D0 : 8) * H + (D0 > 0 ? D0 : 8))[D0 > 0 ? D0 : 8];
+    const float out = part + bias_out;
+    if (live && k == 0) {
+        computed[i] = out;
+        applied[i] = dc_motor_clip(out, vel, saturation, elim[i], vlim[i]);
+    }
+}
+
 // ActuatorNetMLP: the (N, history, J) queues of position error and velocity are rolled by one and topped up (:164-170); the inputs of
 // sample (env, joint) are the entries `input_idx` of both queues, scaled, position block first or second (:172-188).
 __global__ void __launch_bounds__(64)
@@ -623,6 +714,20 @@ extern "C" int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hid
     // the ANYdrive shapes run from registers (k_actuator_net_lstm_reg); anything else through the generic LDS kernel
     if (hidden == 8 && num_lstm <= 4 && (reinterpret_cast<uintptr_t>(hidden_state_d) & 15) == 0 && (reinterpret_cast<uintptr_t>(cell_state_d) & 15) == 0 &&
         ((num_dense == 1) || (num_dense == 2 && (dense_out_h[0] == 16 || dense_out_h[0] == 32)))) {
+        if (getenv("IMX_LSTM_KERNEL") == nullptr || getenv("IMX_LSTM_KERNEL")[0] != 'r') {  // default: eight lanes per sample
+            const unsigned g8 = (unsigned)((n * 8 + 255) / 256);
+            const size_t lds8 = (size_t)num_weights * sizeof(float);
+#define IMX_LSTM_LANES(D0)                                                                                                                \
+    hipLaunchKernelGGL((k_actuator_net_lstm_lanes<D0>), dim3(g8), dim3(256), lds8, (hipStream_t)stream, n, num_lstm, act, (int)num_weights, \
+                       weights_d, joint_pos_target_d, joint_pos_d, joint_vel_d, hidden_state_d, cell_state_d, saturation_effort,         \
+                       effort_limit_d, velocity_limit_d, computed_effort_d, applied_effort_d)
+            if (num_dense == 1) IMX_LSTM_LANES(0);
+            else if (dense_out_h[0] == 16) IMX_LSTM_LANES(16);
+            else IMX_LSTM_LANES(32);
+#undef IMX_LSTM_LANES
+            IMX_HIP(hipGetLastError());
+            return 0;
+        }
         const unsigned grid = (unsigned)((n + 255) / 256);
 #define IMX_LSTM_REG(D0)                                                                                                                  \
     hipLaunchKernelGGL((k_actuator_net_lstm_reg<8, D0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n, num_lstm, act, weights_d,      \
