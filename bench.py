@@ -198,7 +198,7 @@ def time_obs_kernel(env, launches=200):
     def one():
         feed.advance()
         env._bufs.scratch = blocks[feed.index].data_ptr()
-        env._compute_observations(frame_current=True)  # the observation kernel alone, as in env.step()
+        env._compute_observations(frame_current=True, finish_step_tail=env.defer_step_tail)  # the launch env.step() makes (step tail included)
 
     try:
         us = _events_us(one, launches, dev)

@@ -31,8 +31,8 @@ for key, pat in (("k_obs", "k_obs"), ("k_term_rew", "k_term_rew"), ("k_action", 
         out[key] = {"FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0]}
         out[key + "_bytes_per_launch"] = int((2.0 * f[0] + w[0]) * 1024)
         out[key + "_uncorrected_bytes_per_launch"] = int((f[0] + w[0]) * 1024)
-cal_f = [v for (n, c), v in fetch.items() if "elementwise" in n and c == "FETCH_SIZE"]
-cal_w = [v for (n, c), v in write.items() if "elementwise" in n and c == "WRITE_SIZE"]
+cal_f = [v for (n, c), v in fetch.items() if "copyBuffer" in n and c == "FETCH_SIZE"]
+cal_w = [v for (n, c), v in write.items() if "copyBuffer" in n and c == "WRITE_SIZE"]
 out["calibration_copy_KiB"] = {"FETCH_SIZE_mean_over_copy_kernels": cal_f, "WRITE_SIZE_mean_over_copy_kernels": cal_w}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
