@@ -1142,6 +1142,9 @@ class ManagerBasedRLEnv:
         if self._ext_funcs["rew"] or self._ext_funcs["term"]:
             self._eval_external("term")
             self._eval_external("rew")
+        if self._has_orchestration and not self.defer_step_tail:
+            raise RuntimeError("an env that owns its Event / Command / Curriculum managers needs the deferred step tail (defer_step_tail=True): "
+                               "the Metrics/* and Curriculum/* log entries are reduced after the orchestration launch")
         # flag 1: the end of the step (ordered reset ids, reset count, Episode_* log) is finished by an extra workgroup of the
         # observation kernel below -- same stream, kernel boundary in between -- instead of a fence + ticket in this launch
         self._bufs.scan_drift_feed = _lib.ptr(self._scan_drift_feed)  # the step kernel advances the sensor clock (resets draw a drift)
