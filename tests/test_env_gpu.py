@@ -480,6 +480,84 @@ def test_orchestration_in_kernel_draws_and_graph_capture():
     assert all(torch.equal(x, y) for x, y in zip(out[0], out[1])), "same seed, same rollout"
 
 
+def test_runner_logs_metrics_and_curriculum_of_an_env_with_its_own_managers(tmp_path):
+    """OnPolicyRunner.learn over an env that owns its Event / Command / Curriculum managers (three-launch rollout in a hipGraph, the
+    orchestration launch inside it): the per-iteration means of ``Metrics/<command>/*`` and ``Curriculum/terrain_levels`` reach the
+    scalar log next to ``Episode_Reward/*`` (manager_based_rl_env.py:365-389 -> upstream runner's ep_infos), all summed on the device."""
+    import json as _json
+
+    from _util import OrchGolden
+    from isaaclab_amd.rsl_rl import OnPolicyRunner, RslRlVecEnvWrapper
+
+    g = OrchGolden()
+    env = _orch_env(g, seed=3)
+    venv = RslRlVecEnvWrapper(env)
+    runner = OnPolicyRunner(venv, dict(g.fixture["agent"], num_steps_per_env=49), log_dir=str(tmp_path), device="cuda:0", use_graph=True)  # (49 snapshots in the recorded feed: the graph bakes one pass over them)
+    assert runner._fusable()
+    venv.episode_length_buf = g.t("reset/episode_length_buf")
+    import os as _os
+
+    _os.environ["IMX_RUNNER_QUIET"] = "1"
+    try:
+        runner.learn(3)
+    finally:
+        _os.environ.pop("IMX_RUNNER_QUIET", None)
+    last = runner.writer.last
+    for key in ("Metrics/base_velocity/error_vel_xy", "Metrics/base_velocity/error_vel_yaw", "Curriculum/terrain_levels",
+                "Episode_Reward/track_lin_vel_xy_exp", "Episode_Termination/time_out", "Perf/total_fps"):
+        assert key in last and last[key] == last[key], key
+    R = g.meta["terrain"]["rows"]
+    assert 0.0 <= last["Curriculum/terrain_levels"] <= R - 1 and last["Metrics/base_velocity/error_vel_xy"] >= 0.0
+    rows = [_json.loads(ln) for ln in open(_os.path.join(str(tmp_path), "scalars.jsonl"))]
+    assert sum(r["tag"] == "Curriculum/terrain_levels" for r in rows) == 3
+    env.close()
+
+
+def test_orchestration_subsets_and_guards():
+    """Parts of the orchestration on their own (a global-time push only; events without a command term), the events given as the cfg's own
+    section, unknown terms refused by name, the non-deferred step tail refused for an env with its own managers."""
+    import copy
+
+    from isaaclab_amd.env import ManagerBasedRLEnv
+    from isaaclab_amd.events import EventManager
+    from isaaclab_amd.robots import ANYMAL_C
+
+    g = Golden("Isaac-Velocity-Flat-Anymal-C-v0")
+    push = {"func": "isaaclab.envs.mdp.events:push_by_setting_velocity", "mode": "interval", "interval_range_s": (0.03, 0.05), "is_global_time": True,
+            "params": {"velocity_range": {"x": (-0.5, 0.5)}}}
+    env = ManagerBasedRLEnv(g.fixture, state_feed=g.feed("cuda:0"), events_cfg={"push_all": push, "startup_thing": {"func": "x:randomize_rigid_body_material", "mode": "startup", "params": {}}})
+    assert env.event_manager.active_terms == {"interval": ["push_all"]} and env.event_manager.skipped_terms == ["startup_thing"]
+    assert env.command_term is None and env.curriculum_manager is None
+    env.reset()
+    a = torch.zeros(64, 12, device="cuda:0")
+    fired = 0
+    for _ in range(6):
+        before = env.sim_writes["root_vel"].clone()
+        env.step(a)
+        changed = (env.sim_writes["root_vel"] != before).any(dim=1)
+        assert bool(changed.all()) or not bool(changed.any())  # one timer: every env at once, or none
+        if bool(changed.all()):
+            fired += 1
+            d = env.sim_writes["root_vel"][:, 0] - env.feed["root_lin_vel_w"][:, 0]
+            assert float(d.abs().max()) <= 0.5 + 1e-6 and torch.equal(env.sim_writes["root_vel"][:, 1], env.feed["root_lin_vel_w"][:, 1])
+    assert 2 <= fired <= 4  # 0.02 s steps, a new interval of 0.03..0.05 s after every push
+    with pytest.raises(RuntimeError, match="deferred step tail"):
+        env.defer_step_tail = False
+        env.step(a)
+    env.close()
+    with pytest.raises(NotImplementedError, match="randomize_actuator_gains"):
+        EventManager({"t": {"func": "isaaclab.envs.mdp.events:randomize_actuator_gains", "mode": "reset", "params": {}}}, 8, ANYMAL_C, "cuda:0")
+    with pytest.raises(ValueError, match="interval_range_s"):
+        EventManager({"t": dict(push, interval_range_s=None)}, 8, ANYMAL_C, "cuda:0")
+    fx = copy.deepcopy(g.fixture)
+    fx["env"]["curriculum"] = {"w": {"func": "isaaclab.envs.mdp.curriculums:modify_reward_weight", "params": {}}}
+    with pytest.raises(NotImplementedError, match="modify_reward_weight"):
+        ManagerBasedRLEnv(fx, state_feed=g.feed("cuda:0"), use_command_term=True, use_curriculum=True,
+                          terrain_importer=__import__("isaaclab_amd.events", fromlist=["x"]).TerrainImporterState(
+                              torch.zeros(2, 2, 3, device="cuda:0"), torch.zeros(64, dtype=torch.long, device="cuda:0"),
+                              torch.zeros(64, dtype=torch.long, device="cuda:0"), 8.0))
+
+
 @pytest.mark.parametrize("mode", ["fused-eager", "fused-graph", "generic-normalized"])
 def test_runner_learn_modes(mode, tmp_path):
     """OnPolicyRunner.learn through the three rollout paths (train.py:167-183 surface), checkpoint round trip."""

@@ -256,3 +256,32 @@ def test_live_reference_cfg_objects_compile_to_the_same_plan():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     res = json.loads(line[len("RESULT "):])
     assert set(res) == set(_LIVE_CFGS) and all(res.values()), res
+
+
+def test_terrain_importer_state_follows_the_reference_layout():
+    """``TerrainImporterState.from_generator_cfg`` = ``TerrainImporter._compute_env_origins_curriculum`` (terrains/terrain_importer.py:328-347):
+    types = floor(arange(N) / (N / num_cols)), levels in [0, max_init_terrain_level], env_origins = origins[level, type]; sub-terrain origins
+    at the tile centres of the generator grid."""
+    import torch
+
+    from isaaclab_amd.events import TerrainImporterState
+
+    cfg = {"num_rows": 10, "num_cols": 20, "size": [8.0, 8.0]}
+    ti = TerrainImporterState.from_generator_cfg(4096, cfg, "cpu", max_init_terrain_level=5)
+    assert ti.terrain_origins.shape == (10, 20, 3) and ti.max_terrain_level == 10 and ti.size_x == 8.0
+    assert torch.equal(ti.terrain_types, torch.div(torch.arange(4096), 4096 / 20, rounding_mode="floor").long())
+    assert int(ti.terrain_levels.min()) >= 0 and int(ti.terrain_levels.max()) <= 5
+    assert torch.equal(ti.env_origins, ti.terrain_origins[ti.terrain_levels, ti.terrain_types])
+    assert torch.allclose(ti.terrain_origins[0, 0, :2], torch.tensor([-36.0, -76.0])) and torch.allclose(ti.terrain_origins[9, 19, :2], torch.tensor([36.0, 76.0]))
+
+
+def test_task_cfg_merges_the_managers_side_file():
+    """The headline task's events / curriculum / robot init state travel in ``<task>.managers.json`` (dumped from the UNMODIFIED reference cfg by
+    oracle/gen_golden_orchestration.py): ``load_task_cfg`` merges it, other tasks are untouched."""
+    from isaaclab_amd.env import load_task_cfg
+
+    fx = load_task_cfg("Isaac-Velocity-Rough-Anymal-C-v0")["env"]
+    assert set(fx["events"]) == {"base_external_force_torque", "reset_base", "reset_robot_joints", "push_robot"}
+    assert fx["events"]["push_robot"]["interval_range_s"] == [10.0, 15.0] and fx["events"]["push_robot"]["mode"] == "interval"
+    assert list(fx["curriculum"]) == ["terrain_levels"] and fx["scene"]["robot"]["init_state"]["pos"] == [0.0, 0.0, 0.6]
+    assert "events" not in load_task_cfg("Isaac-Cartpole-v0")["env"]
