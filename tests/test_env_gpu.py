@@ -545,6 +545,28 @@ def test_orchestration_subsets_and_guards():
         env.defer_step_tail = False
         env.step(a)
     env.close()
+    # reset(env_ids=...) of an env with its own managers: _reset_idx for exactly those envs (commands resampled, counters back to 1,
+    # reset events written), the others untouched; no interval event, no command compute
+    from _util import OrchGolden
+
+    og = OrchGolden()
+    env = _orch_env(og, seed=5)
+    env.reset()
+    env.step(torch.zeros(og.N, 12, device="cuda:0"))
+    ct = env.command_term
+    ct.command_counter += 3
+    before = {k: v.clone() for k, v in env.sim_writes.items()}
+    cmd_before, tl_before = ct.vel_command_b.clone(), env.event_manager.get_term("push_robot").time_left.clone()
+    ids = torch.tensor([2, 9, 40], device="cuda:0")
+    _, extras = env.reset(env_ids=ids)
+    others = torch.ones(og.N, dtype=torch.bool, device="cuda:0")
+    others[ids] = False
+    assert torch.equal(ct.command_counter[ids].cpu(), torch.ones(3, dtype=torch.long)) and bool((ct.command_counter[others] >= 4).all())
+    assert torch.equal(ct.vel_command_b[others], cmd_before[others]) and not torch.equal(ct.vel_command_b[ids], cmd_before[ids])
+    assert torch.equal(env.sim_writes["root_pose"][others], before["root_pose"][others]) and not torch.equal(env.sim_writes["root_pose"][ids], before["root_pose"][ids])
+    assert torch.equal(env.event_manager.get_term("push_robot").time_left, tl_before)  # interval timers belong to step()
+    assert "Metrics/base_velocity/error_vel_xy" in extras["log"] and "Curriculum/terrain_levels" in extras["log"]
+    env.close()
     with pytest.raises(NotImplementedError, match="randomize_actuator_gains"):
         EventManager({"t": {"func": "isaaclab.envs.mdp.events:randomize_actuator_gains", "mode": "reset", "params": {}}}, 8, ANYMAL_C, "cuda:0")
     with pytest.raises(ValueError, match="interval_range_s"):
