@@ -93,9 +93,10 @@ def build_env(task, num_envs, device, seed, snapshots, terrain_tiles, mesh=None,
 
     env = ManagerBasedRLEnv(fx, state_feed=feed, terrain=terrain, terrain_cell=0.1, noise_seed=seed, own_managers=True, use_contact_sensor=True,
                             use_articulation_update=True)
-    lstm, head = anydrive_like_net(device)
-    env.attach_actuator(ActuatorNetLSTM(num_envs, robot.num_joints, 80.0, 7.5, 120.0, lstm_layers=lstm, head=head, head_activation="softsign",
-                                        device=device))
+    if robot.name == "anymal_c":  # ANYDRIVE_3_LSTM_ACTUATOR_CFG (isaaclab_assets/robots/anymal.py:45-51); G1 / Cartpole use implicit actuators
+        lstm, head = anydrive_like_net(device)
+        env.attach_actuator(ActuatorNetLSTM(num_envs, robot.num_joints, 80.0, 7.5, 120.0, lstm_layers=lstm, head=head, head_activation="softsign",
+                                            device=device))
     return fx, env, ntri
 
 

@@ -389,12 +389,17 @@ def main():
         json.dump(gg._jsonable(out), f, indent=1, sort_keys=False)
     # ---- the UNMODIFIED events / curriculum / robot init state of the velocity tasks (velocity_env_cfg.py:150-226,290-296): bench.py
     #      --full-step runs the headline task with the env's own managers, and the task JSONs of gen_golden.py do not carry these sections
-    base = AnymalCRoughEnvCfg().to_dict()
-    ev = {k: v for k, v in base["events"].items() if v is not None and v.get("mode") in ("reset", "interval")}
-    side = {"events": ev, "curriculum": base["curriculum"],
-            "scene": {"robot": {"init_state": {k: list(v) for k, v in base["scene"]["robot"]["init_state"].items() if k in ("pos", "rot", "lin_vel", "ang_vel")}}}}
-    with open(os.path.join(gg.CONFIGS, "Isaac-Velocity-Rough-Anymal-C-v0.managers.json"), "w") as f:
-        json.dump(gg._jsonable(side), f, indent=1, sort_keys=False)
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.anymal_c.flat_env_cfg import AnymalCFlatEnvCfg
+    from isaaclab_tasks.manager_based.locomotion.velocity.config.g1.rough_env_cfg import G1RoughEnvCfg
+
+    for task_id, cls in (("Isaac-Velocity-Rough-Anymal-C-v0", AnymalCRoughEnvCfg), ("Isaac-Velocity-Flat-Anymal-C-v0", AnymalCFlatEnvCfg),
+                         ("Isaac-Velocity-Rough-G1-v0", G1RoughEnvCfg)):
+        base = cls().to_dict()
+        ev = {k: v for k, v in base["events"].items() if v is not None and v.get("mode") in ("reset", "interval")}
+        side = {"events": ev, "curriculum": base["curriculum"],
+                "scene": {"robot": {"init_state": {k: list(v) for k, v in base["scene"]["robot"]["init_state"].items() if k in ("pos", "rot", "lin_vel", "ang_vel")}}}}
+        with open(os.path.join(gg.CONFIGS, task_id + ".managers.json"), "w") as f:
+            json.dump(gg._jsonable(side), f, indent=1, sort_keys=False)
     np.savez_compressed(os.path.join(gg.GOLDEN, "orchestration.npz"), **rec)
     print("[golden] orchestration:", len(rec), "arrays")
 
