@@ -301,6 +301,7 @@ struct ReduceSeg {
     float* db;
     int S, N;
     unsigned first_block;
+    int vec;  // 1: a thread owns FOUR consecutive outputs (16-byte loads; total, N multiples of 4, 16-byte aligned partials and outputs)
 };
 struct ReduceBatchArgs {
     ReduceSeg seg[RED_MAX_SEG];
@@ -313,6 +314,33 @@ __global__ void __launch_bounds__(64 * RED_Y) k_mlp_reduce_batch(ReduceBatchArgs
     for (int q = 1; q < RED_MAX_SEG; ++q) k += (q < a.n && blockIdx.x >= a.seg[q].first_block) ? 1 : 0;
     const ReduceSeg& g = a.seg[k];
     const int tx = threadIdx.x, ty = threadIdx.y;
+    if (g.vec) {  // four outputs per thread: the same per-output summation order (slices ty, ty + 16, ... then y = 0..15), a quarter of the loads
+        __shared__ float4 red4[RED_Y][64];
+        const int64_t i = ((int64_t)(blockIdx.x - g.first_block) * 64 + tx) * 4;
+        const float* src = nullptr;
+        int64_t stride = 0;
+        float* dst = nullptr;
+        if (i < g.total) {
+            src = g.part + i; stride = g.total; dst = g.out + i;
+        } else if (g.db && i - g.total < g.N) {
+            src = g.part_db + (i - g.total); stride = g.N; dst = g.db + (i - g.total);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src)
+            for (int s = ty; s < g.S; s += RED_Y) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)s * stride);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        red4[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && dst) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int y = 0; y < RED_Y; ++y) { const float4 v = red4[y][tx]; sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
+            *reinterpret_cast<float4*>(dst) = sum;
+        }
+        return;
+    }
     const int64_t i = (int64_t)(blockIdx.x - g.first_block) * 64 + tx;
     const float* src = nullptr;
     int64_t stride = 0;
@@ -599,8 +627,9 @@ int reduce_or_defer(const char* who, int64_t total, int S, const float* part, fl
         IMX_REQUIRE(t_batch->args.n < RED_MAX_SEG, "%s: more than %d deferred reductions in one batch", who, RED_MAX_SEG);
         ReduceSeg& g = t_batch->args.seg[t_batch->args.n++];
         g.total = total; g.part = part; g.out = out; g.part_db = part_db; g.db = db; g.S = S; g.N = N;
+        g.vec = (total % 4 == 0) && (!db || N % 4 == 0) && aligned16(part) && aligned16(out) && (!db || (aligned16(part_db) && aligned16(db)));
         g.first_block = t_batch->blocks;
-        t_batch->blocks += blocks;
+        t_batch->blocks += g.vec ? (unsigned)((threads / 4 + 63) / 64) : blocks;
         return 0;
     }
     hipLaunchKernelGGL(k_mlp_reduce, dim3(blocks), dim3(64, RED_Y), 0, st, total, S, part, out, N, part_db, db);

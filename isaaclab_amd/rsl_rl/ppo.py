@@ -514,8 +514,23 @@ class PPO:
         tr.clear()
         self.policy.reset(dones)
 
+    _critic_infer = None
+
+    def _evaluate(self, critic_obs):
+        """``policy.evaluate`` for the bootstrap values of ``compute_returns``: the critic's whole stack in one launch (``imx_mlp_infer``,
+        one network) where it applies, the module otherwise.  Same arithmetic as the rollout's value estimates."""
+        if self.device.type == "cuda" and critic_obs.is_contiguous() and critic_obs.dtype == torch.float32:
+            if self._critic_infer is None:
+                self._critic_infer = FusedInference(self._critic_layers)
+                self._last_values = torch.empty(critic_obs.shape[0], 1, device=self.device)
+            if self._critic_infer.ok and self._last_values.shape[0] == critic_obs.shape[0]:
+                self._critic_infer.refresh()
+                self._critic_infer(critic_obs, self._last_values)
+                return self._last_values
+        return self.policy.evaluate(critic_obs).detach()
+
     def compute_returns(self, last_critic_obs):
-        last_values = self.policy.evaluate(last_critic_obs).detach()
+        last_values = self._evaluate(last_critic_obs)
         self.storage.compute_returns(last_values, self.gamma, self.lam,
                                      normalize_advantage=not self.normalize_advantage_per_mini_batch)
 
