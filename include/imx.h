@@ -680,6 +680,14 @@ int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const
                       const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                       float* const* out_d, const imx_policy_act_t* act, imx_stream_t stream);
 
+/* First-layer forward of the update with the activation fused: Y (M,N; pitch ldy) = ELU(X W^T + b) (apply_elu = 0: no activation),
+ * X (M,K; pitch ldx), W (N,K) dense row-major, K <= 256 (the observation width: 235, 48, 4 ...).  The layer is bound by WRITING its
+ * output (K is short); a library GEMM + a separate ELU pass writes, reads and writes it again.  Each wave keeps the weight rows of its 32
+ * output columns in registers, the samples stream through LDS in tiles of 32 rows, bias + ELU are applied to the accumulators.  Exact fp32
+ * (v_mfma_f32_32x32x2_f32, k ascending).  nn.Linear + nn.ELU of rsl_rl's ActorCritic MLPs (upstream rsl_rl/modules/actor_critic.py). */
+int imx_mlp_fwd_elu(int64_t M, int N, int K, const float* X_d, int64_t ldx, const float* W_d, const float* b_d, float elu_alpha,
+                    int apply_elu, float* Y_d, int64_t ldy, imx_stream_t stream);
+
 /* Output layer forward, A <= 64 outputs (action means / value): y[M][A] = h W^T + b, h (M,K; pitch ldh), W (A,K).
  * elu_in_place != 0: h_d holds the PRE-activation output of the layer below; h <- ELU(h) (aten elu, alpha = elu_alpha) is
  * applied on the way in and written back in place, so that layer needs no separate activation pass. */

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libimx.so")
-SOURCES = ("core.hip", "mesh.hip", "step.hip", "rollout.hip", "producers.hip", "mlp.hip", "events.hip", "orchestrate.hip")
+SOURCES = ("core.hip", "mesh.hip", "step.hip", "rollout.hip", "producers.hip", "mlp.hip", "mlp_fwd.hip", "events.hip", "orchestrate.hip")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",  # keep the reference's fp32 association: no fused multiply-adds

@@ -202,6 +202,14 @@ def _is_head(lin: nn.Linear, x: torch.Tensor) -> bool:
             and x.stride(1) == 1 and x.stride(0) % 4 == 0)
 
 
+FUSED_FIRST_LAYER_MAX_K = 256  # imx_mlp_fwd_elu keeps a column's weights in registers
+
+
+def fused_first_layer_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous() and w.shape[1] == x.shape[1]
+            and x.shape[1] <= FUSED_FIRST_LAYER_MAX_K and os.getenv("IMX_FUSED_L0", "1") != "0")
+
+
 def mlp_scratch(layers, M: int, device) -> torch.Tensor:
     """Scratch for ``mlp_backward`` (one per network: actor and critic run on two streams at once)."""
     n = max(int(lib().imx_mlp_scratch_bytes(M, lin.out_features, lin.in_features)) for lin, _ in layers)
@@ -263,6 +271,14 @@ def mlp_forward(layers, x, out=None, head_loss=None, first=None):
             if pending_elu is not None:
                 h = F.elu(h, alpha=pending_elu, inplace=True)
                 pending_elu = None
+            # (not when the NEXT layer is the output head: that kernel applies this layer's ELU itself on its way in)
+            if li == 0 and isinstance(act, nn.ELU) and li + 1 < len(layers) - 1 and fused_first_layer_ok(h, lin.weight):
+                z = torch.empty(h.shape[0], lin.out_features, device=h.device)  # Linear + ELU in one launch (imx_mlp_fwd_elu)
+                check(lib().imx_mlp_fwd_elu(h.shape[0], lin.out_features, lin.in_features, h.data_ptr(), h.stride(0), lin.weight.data_ptr(),
+                                            lin.bias.data_ptr(), float(act.alpha), 1, z.data_ptr(), z.stride(0), _lib.current_stream(h.device)))
+                h = z
+                saved.append(h)
+                continue
             z = torch.addmm(lin.bias, h, lin.weight.t())  # GEMM + bias epilogue (hipBLASLt)
         if act is None:
             h = z
@@ -650,10 +666,16 @@ class PPO:
         joint_elu = None
         if self._joint0 is not None and critic_obs.data_ptr() == obs.data_ptr() and critic_obs.shape == obs.shape:
             w0, b0, H0, alpha0 = self._joint0
-            z0 = torch.addmm(b0, obs, w0.t())
+            if fused_first_layer_ok(obs, w0):
+                # bias + ELU in the epilogue of the layer's own MFMA kernel (imx_mlp_fwd_elu): the 100 MB output is written once instead of
+                # written, read and written again by a separate activation pass (library GEMM 106 us + ELU 35 us per minibatch before)
+                z0 = torch.empty(obs.shape[0], 2 * H0, device=obs.device)
+                check(L.imx_mlp_fwd_elu(obs.shape[0], 2 * H0, obs.shape[1], obs.data_ptr(), obs.stride(0), w0.data_ptr(), b0.data_ptr(),
+                                        alpha0, 1, z0.data_ptr(), z0.stride(0), stream))
+            else:
+                z0 = torch.addmm(b0, obs, w0.t())
+                joint_elu = alpha0  # the ELU of each half is applied on ITS network's stream, after the fork
             first_a, first_c = z0[:, :H0], z0[:, H0:]
-            joint_elu = alpha0  # the ELU of each half is applied on ITS network's stream, after the fork (two 17 us passes side by side
-            #                     instead of one 35 us pass with the other stream idle)
         side = self._side_stream()
         main = torch.cuda.current_stream(self.device)
         if side is not None:

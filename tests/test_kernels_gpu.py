@@ -747,3 +747,33 @@ def test_update_through_the_rccl_path_single_rank(libimx):
     finally:
         dist.destroy_process_group()
     assert lr == lr_ref and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K,pitch,w_off", [(24576, 1024, 235, 236, 0), (1000, 512, 48, 48, 0), (77, 96, 4, 4, 0), (4099, 640, 256, 256, 0),
+                                               (64, 1024, 235, 235, 0), (20, 128, 235, 236, 0), (3000, 200, 235, 236, 0), (2049, 256, 200, 200, 0),
+                                               (515, 384, 130, 132, 0), (1500, 256, 235, 236, 1), (700, 130, 48, 48, 3)])
+def test_fused_first_layer_forward_matches_torch(libimx, M, N, K, pitch, w_off):
+    """imx_mlp_fwd_elu (Linear + ELU of the first layer, weights in registers, bias + ELU on the accumulators) against torch's
+    addmm + elu in fp64-checked fp32: ragged tiles, a single tile, column counts that are not multiples of 128 (down to whole waves
+    without a column), a pitch that pads the rows (the pad columns hold NaNs on purpose: they must never reach the result), unaligned
+    rows (4-byte loads), K well below the step count of its kernel (many tile columns to zero), a weight matrix off 16-byte alignment."""
+    from isaaclab_amd import _lib
+
+    g = torch.Generator().manual_seed(M + N + K)
+    xb = torch.full((M, pitch), float("nan"))
+    xb[:, :K] = torch.randn(M, K, generator=g)
+    x = xb.cuda()[:, :K]
+    wflat = torch.full((N * K + 8,), float("nan"))
+    wflat[w_off:w_off + N * K] = torch.randn(N * K, generator=g) / K ** 0.5
+    w, b = wflat.cuda()[w_off:w_off + N * K].view(N, K), torch.randn(N, generator=g).cuda()
+    for elu in (1, 0):
+        y = torch.full((M, N + 3), 7.0, device="cuda")
+        _lib.check(libimx.imx_mlp_fwd_elu(M, N, K, x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), 0.7, elu, y.data_ptr(), y.stride(0),
+                                          torch.cuda.current_stream().cuda_stream))
+        ref = torch.addmm(b.double(), x.double(), w.double().t())
+        if elu:
+            ref = torch.nn.functional.elu(ref, alpha=0.7)
+        assert_close(y[:, :N], ref.float(), 2e-5, f"fused first layer (elu={elu})")
+        assert bool((y[:, N:] == 7.0).all())  # nothing written beyond the N columns
+    with pytest.raises(_lib.ImxError):
+        _lib.check(libimx.imx_mlp_fwd_elu(8, 8, 300, x.data_ptr(), 300, w.data_ptr(), b.data_ptr(), 1.0, 1, y.data_ptr(), 8, 0))

@@ -10,14 +10,12 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 k = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Queue_Id"])) for r in rows]
 k.sort()
 names = [x[2] for x in k]
-# an update = from a k_gather_rows that follows k_gae (first minibatch) to the last k_adam_apply before the next k_obs
+# an update = the kernels between the last k_gae.. of the trace that is followed by a whole update and that update's last k_adam_apply
 adam = [i for i, n in enumerate(names) if n.startswith("k_adam_apply")]
-gae = [i for i, n in enumerate(names) if n.startswith("k_gae")]
-# the last k_gae that is followed by a whole update (bench.py runs secondary measurements after the timed region)
-gath_all = [i for i, n in enumerate(names) if n.startswith("k_gather_rows")]
-last_gae = max(g for g in gae if any(i > g for i in gath_all))
-start = next(i for i in gath_all if i > last_gae)
-nxt_obs = next((i for i in range(start, len(k)) if names[i].startswith("void k_obs") or names[i].startswith("k_obs")), len(k))
+gae = [i for i, n in enumerate(names) if n.startswith("k_gae") or n.startswith("k_adv_normalize")]
+last_gae = max(g for g in gae if sum(1 for i in adam if i > g) >= 20)
+start = last_gae + 1
+nxt_obs = next((i for i in range(start, len(k)) if "k_obs" in names[i] or "k_mlp_infer" in names[i]), len(k))
 end = max(i for i in adam if start < i < nxt_obs)
 seg = k[start:end + 1]
 t0, t1 = seg[0][0], max(x[1] for x in seg)
@@ -36,12 +34,11 @@ tot = t1 - t0
 print("no kernel running %.3f ms (%.1f %%), one %.3f ms (%.1f %%), two or more %.3f ms (%.1f %%)" % (
     busy[0] / 1e6, 100 * busy[0] / tot, busy[1] / 1e6, 100 * busy[1] / tot, busy[2] / 1e6, 100 * busy[2] / tot))
 print("sum of kernel durations %.3f ms" % (sum(e - s for s, e, _, _ in seg) / 1e6))
-# one minibatch in the middle: list kernels with start offset, duration, queue
-gath = [i for i, x in enumerate(seg) if x[2].startswith("k_gather_rows")]
-a, b = gath[10], gath[11]
-m0 = seg[a][0]
-print(f"--- minibatch 10: {(seg[b][0] - m0) / 1e3:.1f} us between its gather and the next one")
+# one minibatch in the middle (minibatches end with k_adam_apply): kernels with start offset, duration, queue
+ends = [i for i, x in enumerate(seg) if x[2].startswith("k_adam_apply")]
+a, b = ends[9] + 1, ends[10]
+m0 = seg[ends[9]][1]
+print(f"--- minibatch 10: {(seg[b][1] - m0) / 1e3:.1f} us from the end of the previous Adam step to the end of its own")
 short = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "")[:44]
-lastend = m0
 for s, e, n, q in seg[a:b + 1]:
     print(f"  +{(s - m0) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  q{q}  {short(n)}")
