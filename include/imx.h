@@ -675,10 +675,19 @@ typedef struct imx_policy_act {
     const imx_buffers_t* buf;
     float pre_clip;                /* RslRlVecEnvWrapper clip_actions or +inf */
 } imx_policy_act_t;
-/* out_d[0] may be NULL when act != NULL (the means go to mu_out_d); act == NULL: plain imx_mlp_infer. */
+/* out_d[0] may be NULL when act != NULL (the means go to mu_out_d); act == NULL: plain imx_mlp_infer.
+ * packed_weights_d (optional, HOST array of device pointers like weights_d): the same weights re-ordered by imx_mlp_pack_weights.  In
+ * the row layout a wave's load instruction reads 16 bytes from each of 32 weight rows; the packed image holds those 64 x 16 bytes
+ * contiguously, in the order the 32-sample kernel consumes them, so every load is one full KiB.  Same values, same arithmetic, same
+ * results; weights_d must still be given (the 16-sample kernel for small M reads the rows). */
 int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
-                      const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
-                      float* const* out_d, const imx_policy_act_t* act, imx_stream_t stream);
+                      const float* const* weights_d, const int* weight_pitch, const float* const* packed_weights_d,
+                      const float* const* biases_d, const float* elu_alpha, float* const* out_d, const imx_policy_act_t* act,
+                      imx_stream_t stream);
+/* Floats of the packed image of an (out_features x in_features) nn.Linear weight (both rounded up to multiples of 32), and the packing
+ * itself (W_d row-major with row pitch ldw >= in_features; packed_d 16-byte aligned; to be repeated whenever the weights change). */
+size_t imx_mlp_packed_floats(int out_features, int in_features);
+int imx_mlp_pack_weights(int out_features, int in_features, const float* W_d, int64_t ldw, float* packed_d, imx_stream_t stream);
 
 /* First-layer forward of the update with the activation fused: Y (M,N; pitch ldy) = ELU(X W^T + b) (apply_elu = 0: no activation),
  * X (M,K; pitch ldx), W (N,K) dense row-major, K <= 256 (the observation width: 235, 48, 4 ...).  The layer is bound by WRITING its

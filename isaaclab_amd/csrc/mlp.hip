@@ -808,6 +808,7 @@ constexpr int INF_ROWS = 32, INF_MAXD = 512, INF_PITCH = INF_MAXD + 4, INF_MAXL 
 
 struct InferNet {
     const float* W[INF_MAXL];
+    const float* Wp[INF_MAXL];  // the same weights in the lane order of the 32-sample kernel (imx_mlp_pack_weights), or null
     const float* b[INF_MAXL];
     int ldw[INF_MAXL];   // row pitch of W (floats): multiple of 32, zero padded
     int dim[INF_MAXL + 1];
@@ -881,7 +882,11 @@ __device__ __forceinline__ void act_epilogue(const ActArgs& c, const float* __re
 // that is a multiple of 32, activation columns beyond K are zero in LDS, column blocks beyond N re-read row N-1 and are
 // dropped in the epilogue): a load inside a divergent branch makes the compiler wait for all outstanding loads at the
 // join, which measured 2x slower here.
-template <int NBW>
+// PACKED: W points at the packed copy (imx_mlp_pack_weights): chunk ((cb * nsub + sc) * 4 + i) holds, lane by lane, exactly the float4
+// the row layout's load (column block cb, sub-group sc, piece i) gives each lane -- one contiguous KiB per wave instruction instead of
+// 32 rows x 2 x 16 bytes.  Lanes reading 32 different weight rows is what held this kernel at ~4 TB/s of L2 traffic (256 workgroups x
+// 1.1 MB of weights per launch); contiguous pieces stream from L2 at several times that.
+template <int NBW, bool PACKED>
 __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K, const float* __restrict__ W, int ldw,
                                             const float* __restrict__ bias, int N, bool elu, float alpha, float* __restrict__ sOut,
                                             float* __restrict__ gOut, int64_t m0, int64_t M) {
@@ -901,9 +906,15 @@ __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K
     const float* wrow[NBW];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
-        const int n = (w + 4 * j) * 32 + r;
-        wrow[j] = W + (size_t)(n < N ? n : N - 1) * ldw + 16 * half;
+        if (PACKED) {
+            const int ncb = (N + 31) >> 5, cb = w + 4 * j;
+            wrow[j] = W + ((size_t)(cb < ncb ? cb : ncb - 1) * nsub * 4) * 256 + 4 * lane;  // (blocks past N re-read the last one; dropped below)
+        } else {
+            const int n = (w + 4 * j) * 32 + r;
+            wrow[j] = W + (size_t)(n < N ? n : N - 1) * ldw + 16 * half;
+        }
     }
+    constexpr int WSTEP_SC = PACKED ? 4 * 256 : 32, WSTEP_I = PACKED ? 256 : 4;  // floats between sub-groups / between the four pieces
     const float* arow = sIn + r * INF_PITCH + 16 * half;
     float4 Pa[GS][4], Qa[GS][4], Pb[NBW][GS][4], Qb[NBW][GS][4];
     // sub-groups past the end (a group may be partial) are clamped to the last one for the loads and multiplied by zero
@@ -915,7 +926,7 @@ __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K
 #pragma unroll
             for (int j = 0; j < NBW; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[j][u][i] = *reinterpret_cast<const float4*>(wrow[j] + 32 * sc + 4 * i);
+                for (int i = 0; i < 4; ++i) b[j][u][i] = *reinterpret_cast<const float4*>(wrow[j] + WSTEP_SC * sc + WSTEP_I * i);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float4 v = *reinterpret_cast<const float4*>(arow + 32 * sc + 4 * i);
@@ -980,6 +991,7 @@ __device__ __forceinline__ void infer_layer(const float* __restrict__ sIn, int K
     }
 }
 
+template <bool PACKED>
 __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a, ActArgs act) {
     extern __shared__ float smem[];  // two activation buffers of INF_ROWS x INF_PITCH floats
     float* buf0 = smem;
@@ -991,32 +1003,35 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a, ActArgs act) 
     // input rows -> LDS (the 32 rows are one contiguous run when ldx == dim[0]); columns up to the next multiple of 32 are zeroed
     const int K0 = net.dim[0], K0p = (K0 + 31) & ~31;
     {
-        // wave w takes rows w, w+4, ...; lanes run along the row.  All loads of a half tile are issued before the first LDS
-        // store (a load -> store loop pays one HBM round trip per iteration: 16 us for 235 columns).
+        // wave w takes rows w, w+4, ...; lanes run along the row.  ALL loads of the tile are issued before the first LDS store -- one HBM
+        // round trip for the whole input (a load -> store loop pays one per iteration: 16 us for 235 columns; two half tiles paid two) --
+        // and only the 64-column pieces the input has (a clamped load of a piece past K0 is still a memory request).
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int ncc = (K0 + 63) >> 6;  // (uniform)
+        float v[8][INF_MAXD / 64];
 #pragma unroll
-        for (int hrow = 0; hrow < 2; ++hrow) {
-            float v[4][INF_MAXD / 64];
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = w + 4 * rr;
+            const float* src = a.X + (m0 + row < a.M ? m0 + row : 0) * a.ldx;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = w + 4 * (rr + 4 * hrow);
-                const float* src = a.X + (m0 + row < a.M ? m0 + row : 0) * a.ldx;
-#pragma unroll
-                for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+            for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                if (cc < ncc) {
                     const int c = lane + 64 * cc;
-                    const float x = src[c < K0 ? c : 0];  // clamped, unconditional
+                    const float x = src[c < K0 ? c : 0];  // clamped, unconditional within the piece
                     v[rr][cc] = (c < K0 && m0 + row < a.M) ? x : 0.0f;
+                } else {
+                    v[rr][cc] = 0.0f;
                 }
             }
+        }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = w + 4 * (rr + 4 * hrow);
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = w + 4 * rr;
 #pragma unroll
-                for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
-                    const int c = lane + 64 * cc;
-                    if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
-                    if (act_here && c < K0 && m0 + row < a.M) act.obs_out[(m0 + row) * (int64_t)K0 + c] = v[rr][cc];  // storage.observations[t]
-                }
+            for (int cc = 0; cc < INF_MAXD / 64; ++cc) {
+                const int c = lane + 64 * cc;
+                if (c < K0p) buf0[row * INF_PITCH + c] = v[rr][cc];
+                if (act_here && c < K0 && m0 + row < a.M) act.obs_out[(m0 + row) * (int64_t)K0 + c] = v[rr][cc];  // storage.observations[t]
             }
         }
     }
@@ -1035,9 +1050,10 @@ __global__ void __launch_bounds__(256, 1) k_mlp_infer(InferArgs a, ActArgs act) 
                 out[row * INF_PITCH + col] = 0.0f;
             }
         }
-        if (nbw <= 1) infer_layer<1>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
-        else if (nbw == 2) infer_layer<2>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
-        else infer_layer<4>(in, K, net.W[l], net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        const float* Wl = PACKED ? net.Wp[l] : net.W[l];
+        if (nbw <= 1) infer_layer<1, PACKED>(in, K, Wl, net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else if (nbw == 2) infer_layer<2, PACKED>(in, K, Wl, net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
+        else infer_layer<4, PACKED>(in, K, Wl, net.ldw[l], net.b[l], N, !last, net.alpha, so, net.out, m0, a.M);
         __syncthreads();
         float* t = in; in = out; out = t;
     }
@@ -1204,12 +1220,48 @@ __global__ void __launch_bounds__(256, 2) k_mlp_infer16(InferArgs a, ActArgs act
 extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
                              const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
                              float* const* out_d, imx_stream_t stream) {
-    return imx_mlp_infer_act(M, X_d, ldx, nnets, nlayers, dims, weights_d, weight_pitch, biases_d, elu_alpha, out_d, nullptr, stream);
+    return imx_mlp_infer_act(M, X_d, ldx, nnets, nlayers, dims, weights_d, weight_pitch, nullptr, biases_d, elu_alpha, out_d, nullptr, stream);
+}
+
+// one thread per float4 of the packed image
+__global__ void k_pack_weights(int N, int K, const float* __restrict__ W, int64_t ldw, float* __restrict__ out, int nsub, int64_t total4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    const int lane = (int)(t & 63);
+    const int64_t chunk = t >> 6;
+    const int i = (int)(chunk & 3), sc = (int)((chunk >> 2) % nsub), cb = (int)((chunk >> 2) / nsub);
+    const int r = lane & 31, half = lane >> 5;
+    const int n = cb * 32 + r, k0 = 32 * sc + 16 * half + 4 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+        const float* src = W + (size_t)n * ldw + k0;
+        if (k0 + 0 < K) v.x = src[0];
+        if (k0 + 1 < K) v.y = src[1];
+        if (k0 + 2 < K) v.z = src[2];
+        if (k0 + 3 < K) v.w = src[3];
+    }
+    reinterpret_cast<float4*>(out)[t] = v;
+}
+
+extern "C" size_t imx_mlp_packed_floats(int out_features, int in_features) {
+    return (size_t)((out_features + 31) / 32 * 32) * (size_t)((in_features + 31) / 32 * 32);
+}
+
+extern "C" int imx_mlp_pack_weights(int out_features, int in_features, const float* W_d, int64_t ldw, float* packed_d, imx_stream_t stream) {
+    IMX_REQUIRE(out_features > 0 && in_features > 0 && W_d && packed_d && ldw >= in_features, "imx_mlp_pack_weights: bad arguments");
+    IMX_REQUIRE(aligned16(packed_d), "imx_mlp_pack_weights: the packed image must be 16-byte aligned");
+    const int nsub = (in_features + 31) / 32;
+    const int64_t total4 = (int64_t)imx_mlp_packed_floats(out_features, in_features) / 4;
+    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_features, in_features, W_d,
+                       ldw, packed_d, nsub, total4);
+    IMX_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,
-                                 const float* const* weights_d, const int* weight_pitch, const float* const* biases_d, const float* elu_alpha,
-                                 float* const* out_d, const imx_policy_act_t* pa, imx_stream_t stream) {
+                                 const float* const* weights_d, const int* weight_pitch, const float* const* packed_weights_d,
+                                 const float* const* biases_d, const float* elu_alpha, float* const* out_d, const imx_policy_act_t* pa,
+                                 imx_stream_t stream) {
     IMX_REQUIRE(M > 0 && X_d && nnets >= 1 && nnets <= 2 && nlayers && dims && weights_d && biases_d && elu_alpha && out_d,
                 "imx_mlp_infer: bad arguments");
     ActArgs act{};
@@ -1248,6 +1300,8 @@ extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int n
                     a.net[0].dim[0], (long long)ldx);
         for (int l = 0; l < n.nlayers; ++l) {
             n.W[l] = weights_d[wi];
+            n.Wp[l] = packed_weights_d ? packed_weights_d[wi] : nullptr;
+            IMX_REQUIRE(!packed_weights_d || (n.Wp[l] && aligned16(n.Wp[l])), "imx_mlp_infer: null / unaligned packed weights (network %d, layer %d)", k, l);
             n.b[l] = biases_d[wi];
             n.ldw[l] = weight_pitch ? weight_pitch[wi] : n.dim[l];
             ++wi;
@@ -1267,7 +1321,9 @@ extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int n
     const bool small = (int64_t)a.tiles * nnets * 2 <= g_num_cu;
     static bool attr_set = false;
     if (!attr_set) {
-        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer), hipFuncAttributeMaxDynamicSharedMemorySize,
+        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2ull * INF_ROWS * INF_PITCH * sizeof(float))));
+        IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(2ull * INF_ROWS * INF_PITCH * sizeof(float))));
         IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_infer16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(2ull * INF16_ROWS * INF_PITCH * sizeof(float))));
@@ -1277,8 +1333,11 @@ extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int n
         a.tiles = (int)((M + INF16_ROWS - 1) / INF16_ROWS);
         hipLaunchKernelGGL(k_mlp_infer16, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF16_ROWS * INF_PITCH * sizeof(float),
                            (hipStream_t)stream, a, act);
+    } else if (packed_weights_d) {
+        hipLaunchKernelGGL(k_mlp_infer<true>, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF_ROWS * INF_PITCH * sizeof(float),
+                           (hipStream_t)stream, a, act);
     } else {
-        hipLaunchKernelGGL(k_mlp_infer, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF_ROWS * INF_PITCH * sizeof(float),
+        hipLaunchKernelGGL(k_mlp_infer<false>, dim3((unsigned)(a.tiles * nnets)), dim3(256), 2ull * INF_ROWS * INF_PITCH * sizeof(float),
                            (hipStream_t)stream, a, act);
     }
     IMX_HIP(hipGetLastError());

@@ -166,6 +166,11 @@ class FusedInference:
                 self._padded.append((buf, w))
                 pitch.append(kp)
                 wp.append(buf)
+        # ... and every layer a PACKED copy in the lane order of the 32-sample kernel (imx_mlp_pack_weights): one contiguous KiB per load
+        # instruction instead of 16 bytes from each of 32 rows; refreshed with the padded copies
+        L = lib()
+        self._packed = [torch.zeros(int(L.imx_mlp_packed_floats(w.shape[0], w.shape[1])), device=w.device, dtype=w.dtype) for w in ws]
+        self._wpk = (ctypes.c_void_p * len(ws))(*[b.data_ptr() for b in self._packed]) if os.getenv("IMX_INFER_PACKED", "1") != "0" else None
         self._keep = (ws, bs, wp)
         self._nl = (ctypes.c_int * len(nl))(*nl)
         self._dims = (ctypes.c_int * len(dims))(*dims)
@@ -182,6 +187,10 @@ class FusedInference:
         """Re-copy the padded weight buffers from the live parameters (capturable: plain device copies)."""
         for buf, w in self._padded:
             buf[:, :w.shape[1]].copy_(w)
+        if self._wpk is not None:
+            st = _lib.current_stream(self._packed[0].device)
+            for buf, w in zip(self._packed, self._keep[0]):
+                check(lib().imx_mlp_pack_weights(w.shape[0], w.shape[1], w.data_ptr(), w.stride(0), buf.data_ptr(), st))
 
     def __call__(self, x: torch.Tensor, *outs: torch.Tensor, act=None):
         """``act``: an ``ImxPolicyAct`` -- the actor's workgroups then also sample the action, write the transition into the storage
@@ -189,8 +198,8 @@ class FusedInference:
         if x.stride(1) != 1 or x.shape[1] != self.in_features or any(o is not None and not o.is_contiguous() for o in outs):
             raise _lib.ImxError("imx_mlp_infer needs a row-major input and contiguous outputs")
         out_p = (self._ctypes.c_void_p * self._n)(*[None if o is None else o.data_ptr() for o in outs])
-        check(lib().imx_mlp_infer_act(x.shape[0], x.data_ptr(), x.stride(0), self._n, self._nl, self._dims, self._w, self._pitch, self._b,
-                                      self._alpha, out_p, self._ctypes.byref(act) if act is not None else None,
+        check(lib().imx_mlp_infer_act(x.shape[0], x.data_ptr(), x.stride(0), self._n, self._nl, self._dims, self._w, self._pitch, self._wpk,
+                                      self._b, self._alpha, out_p, self._ctypes.byref(act) if act is not None else None,
                                       _lib.current_stream(x.device)))
 
 

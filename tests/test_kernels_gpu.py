@@ -286,6 +286,14 @@ def test_mlp_infer_matches_torch(libimx, M, D, hidden, A):
             p.mul_(1.5)
     inf.refresh()
     inf(x, mu, val)
+    # the packed weight images (imx_mlp_pack_weights: the 32-sample kernel's loads made contiguous) change where the bytes come from,
+    # nothing else: bit-identical to the row layout
+    assert inf._wpk is not None
+    packed, inf._wpk = inf._wpk, None
+    mu_r, val_r = torch.full_like(mu, float("nan")), torch.full_like(val, float("nan"))
+    inf(x, mu_r, val_r)
+    inf._wpk = packed
+    assert torch.equal(mu, mu_r) and torch.equal(val, val_r)
     ref_mu = pol.actor.double()(x.double())
     ref_v = pol.critic.double()(x.double())
     assert float((mu.double() - ref_mu).abs().max()) <= 1e-5 * max(1.0, float(ref_mu.abs().max()))
