@@ -731,6 +731,15 @@ int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, const float* h_
                      int has_activation, float* dprev_d, float* dW_d, float* db_d, void* scratch_d, size_t scratch_bytes,
                      imx_stream_t stream);
 
+/* imx_mlp_head_fwd_loss and imx_mlp_head_bwd in one pass over the last hidden layer's output z (M,K; pitch ldz; K = 128 or 256, A <= 16):
+ * h = ELU(z) when elu_in != 0 (else h = z), y = h W^T + b, the loss gradient dY from y (loss->mode 1 or 2, written to loss->dmu_d /
+ * dsigma_d / dvalue_d as imx_mlp_head_fwd_loss does), dprev = (dY W) * ELU'(h), dW = dY^T h, db = colsum(dY).  z is only read: the
+ * activated values never travel to memory (the split pair wrote them in place and read them again).  defer_to: a reduce batch to
+ * queue the reduction of the split partials on (NULL: the batch open on this thread, or an immediate launch). */
+int imx_mlp_head_fwd_bwd(int64_t M, int K, int A, const float* z_d, int64_t ldz, const float* W_d, const float* b_d, float* y_d,
+                         int elu_in, float elu_alpha, const imx_head_loss_t* loss, float* dprev_d, float* dW_d, float* db_d,
+                         void* scratch_d, size_t scratch_bytes, imx_reduce_batch_t* defer_to, imx_stream_t stream);
+
 /* ---- reset / interval events and terrain curriculum, masked: only rows with mask != 0 are rewritten
  * (mask NULL = every env).  The reference runs these on a compacted env_ids list (EventManager.apply,
  * managers/event_manager.py:150-273); draws are sample_uniform (utils/math.py:1313) = u*(hi-lo)+lo with u from the

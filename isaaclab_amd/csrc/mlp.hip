@@ -584,6 +584,262 @@ __global__ void __launch_bounds__(512) k_head_bwd(int64_t M, int K, int A, const
     }
 }
 
+// Output layer forward, loss gradient and backward in ONE pass over the activations of the last hidden layer (k_head_fwd + k_head_bwd
+// read and wrote them four times between them: ELU in place, then the saved output again).  Per block of 32 samples the workgroup
+//   P0  stores ELU(z) of the tile (prefetched into registers one block ahead) to LDS,
+//   P1  forms the outputs (K/16 lanes per sample, float4 dot products against the weights in LDS, shuffle reduction), writes them and --
+//       one lane per sample -- the loss gradient dY straight from them (line by line k_head_fwd's LOSS branches), into LDS and to global,
+//   P2  is k_head_bwd on that block with both operands out of LDS: dX = dY W on the matrix core, times ELU'(h), and dW += dY^T h.
+// Nothing but the outputs, the loss gradient and dprev is written; two barriers per block.
+template <int K, int AMAX, int LOSS, bool ELU_IN>
+__global__ void __launch_bounds__(2 * K) k_head_fused(int64_t M, int A, const float* __restrict__ z, int64_t ldz, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float alpha, float* __restrict__ y, imx_head_loss_t L,
+                                                      float* __restrict__ dprev, float* __restrict__ part, float* __restrict__ part_db) {
+    constexpr int AB = (AMAX + 31) / 32;  // 32-output blocks of the dW accumulator
+    extern __shared__ float smem[];
+    constexpr int P = K + 32;
+    const int PA = A | 1;                        // row pitches: h tile (b128 reads of 2 rows x 8 parts cover the 64 banks), dY slab (odd)
+    float* sW = smem;                            // [A][K]
+    float* sh = sW + ((A * K + 3) & ~3);         // [2][32][P]
+    float* sdy = sh + 2 * 32 * P;                // [32][PA]
+    float* sbs = sdy + 32 * PA;                  // [2][AMAX]: bias, shared sigma
+    constexpr int T = 2 * K;                     // threads = K / 32 waves
+    const int lane = threadIdx.x & 63, kb = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+    const int kc = kb * 32 + r;                  // backward: this lane's in-feature
+    constexpr int tpr = T >> 5;                  // forward: lanes per sample (K / 16: a power of two)
+    const int frow = threadIdx.x / tpr, fpart = threadIdx.x - frow * tpr;
+    for (int i = threadIdx.x; i < A * K; i += T) sW[i] = W[i];
+    if (threadIdx.x < AMAX) {
+        sbs[threadIdx.x] = threadIdx.x < A ? bias[threadIdx.x] : 0.0f;
+        if (LOSS == 1) sbs[AMAX + threadIdx.x] = (threadIdx.x < A && L.sigma_stride == 0) ? L.sigma_d[threadIdx.x] : 1.0f;
+    }
+    const int steps = (A + 1) >> 1;
+    float wreg[AB * 16];
+#pragma unroll
+    for (int s = 0; s < AB * 16; ++s) {
+        const int o = 2 * s + half;
+        wreg[s] = (s < steps && o < A) ? W[o * K + kc] : 0.0f;
+    }
+    f32x16 wacc[AB];
+    float dbacc[AB];
+#pragma unroll
+    for (int b = 0; b < AB; ++b) {
+        dbacc[b] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wacc[b][q] = 0.0f;
+    }
+    constexpr int kq = K >> 2;  // float4 per row
+    const int64_t nblk = (M + 31) / 32;
+    float4 zt[4];
+    // The loss inputs, prefetched with the tile (a load inside P1 would put a memory round trip between the two barriers of every block).
+    // Policy loss: the K/16 lanes of a sample share its outputs -- lane `fpart` takes outputs fpart, fpart + tpr, ... -- so every lane
+    // holds the actions (and per-sample sigmas) of ITS outputs only; value loss: one lane per sample.
+    constexpr int JCAP = LOSS == 1 ? (AMAX + tpr - 1) / tpr : 1;  // outputs per lane
+    float la[JCAP], ls[JCAP], l0 = 0.0f, l1 = 0.0f;        // (as loaded for the NEXT block; P0 takes copies)
+    const bool own_sigma = LOSS == 1 && L.sigma_stride != 0;
+    auto load_tile = [&](int64_t rb) {
+        {
+            const int64_t grow = rb * 32 + frow < M ? rb * 32 + frow : M - 1;
+            if (LOSS == 1) {
+#pragma unroll
+                for (int j = 0; j < JCAP; ++j) {
+                    const int o = fpart + tpr * j;
+                    la[j] = L.actions_d[grow * A + (o < A ? o : 0)];
+                    ls[j] = own_sigma ? L.sigma_d[grow * A + (o < A ? o : 0)] : 0.0f;
+                }
+                l0 = L.old_logp_d[grow];
+                l1 = L.advantages_d[grow];
+            } else {
+                l0 = L.returns_d[grow];
+                l1 = L.use_clipped_value_loss ? L.old_values_d[grow] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + T * i;
+            const int row = idx / kq, c4 = idx - row * kq;
+            const int64_t grow = rb * 32 + row;
+            zt[i] = *reinterpret_cast<const float4*>(z + (grow < M ? grow : M - 1) * ldz + 4 * c4);  // (rows past M: re-read, never used)
+        }
+    };
+    if ((int64_t)blockIdx.x < nblk) load_tile(blockIdx.x);
+    int buf = 0;
+    for (int64_t rb = blockIdx.x; rb < nblk; rb += gridDim.x, buf ^= 1) {
+        const int64_t m0 = rb * 32;
+        float* th = sh + buf * 32 * P;
+        // ---- P0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + T * i;
+            const int row = idx / kq, c4 = idx - row * kq;
+            float4 hv = zt[i];
+            if (ELU_IN) {
+                const float ex = (expf(fminf(hv.x, 0.0f)) - 1.0f) * alpha, ey = (expf(fminf(hv.y, 0.0f)) - 1.0f) * alpha;
+                const float ez = (expf(fminf(hv.z, 0.0f)) - 1.0f) * alpha, ew = (expf(fminf(hv.w, 0.0f)) - 1.0f) * alpha;
+                hv.x = hv.x > 0.0f ? hv.x : ex; hv.y = hv.y > 0.0f ? hv.y : ey; hv.z = hv.z > 0.0f ? hv.z : ez; hv.w = hv.w > 0.0f ? hv.w : ew;
+            }
+            *reinterpret_cast<float4*>(th + row * P + 4 * c4) = hv;
+        }
+        float ca[JCAP], cs[JCAP];
+#pragma unroll
+        for (int j = 0; j < JCAP; ++j) { ca[j] = la[j]; cs[j] = ls[j]; }
+        const float c0 = l0, c1 = l1;
+        if (rb + gridDim.x < nblk) load_tile(rb + gridDim.x);  // in flight during P1 and P2
+        __syncthreads();
+        // ---- P1
+        {
+            float acc[AMAX];
+#pragma unroll
+            for (int o = 0; o < AMAX; ++o) acc[o] = 0.0f;
+#pragma unroll
+            for (int k0 = 0; k0 < K; k0 += 4 * tpr) {
+                const int k = k0 + 4 * fpart;
+                const float4 hv = *reinterpret_cast<const float4*>(th + frow * P + k);
+#pragma unroll
+                for (int o = 0; o < AMAX; ++o)
+                    if (o < A) {
+                        const float4 wv = *reinterpret_cast<const float4*>(sW + o * K + k);
+                        acc[o] = fmaf(hv.w, wv.w, fmaf(hv.z, wv.z, fmaf(hv.y, wv.y, fmaf(hv.x, wv.x, acc[o]))));
+                    }
+            }
+#pragma unroll
+            for (int o = 0; o < AMAX; ++o)
+                if (o < A) {
+                    float v = acc[o];
+#pragma unroll
+                    for (int off = 1; off < tpr; off <<= 1) v += __shfl_xor(v, off);
+                    acc[o] = v + sbs[o];
+                }
+            const int64_t row = m0 + frow;
+            const bool live = row < M;
+            if (fpart == 0 && live) {
+#pragma unroll
+                for (int o = 0; o < AMAX; ++o)
+                    if (o < A) y[row * A + o] = acc[o];
+            }
+            if (LOSS == 1) {
+                // every lane of the sample holds all A outputs (the xor butterfly leaves the sums everywhere) and works on its own
+                const float inv_m = L.grad_scale / (float)M;
+                float mj[JCAP], sj[JCAP];
+                float logp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < JCAP; ++j) {
+                    mj[j] = 0.0f; sj[j] = 1.0f;
+                    if (j * tpr < A) {  // (uniform)
+                        const int o = fpart + tpr * j;
+                        float m = 0.0f, sg = 1.0f;
+#pragma unroll
+                        for (int oo = 0; oo < AMAX; ++oo) {
+                            m = oo == o ? acc[oo] : m;
+                            sg = oo == o ? sbs[AMAX + oo] : sg;
+                        }
+                        if (own_sigma) sg = cs[j];
+                        mj[j] = m; sj[j] = sg;
+                        const float d = ca[j] - m;
+                        logp += o < A ? -(d * d) / (2.0f * sg * sg) - logf(sg) - IMX_HALF_LOG_2PI_F : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < tpr; off <<= 1) logp += __shfl_xor(logp, off);
+                const float ratio = expf(logp - c0);
+                const float ad = c1, clip = L.clip_param;
+                const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                float dsur_dlogp;
+                if (s1 >= s2) dsur_dlogp = -ad * ratio;
+                else dsur_dlogp = (ratio > 1.0f - clip && ratio < 1.0f + clip) ? -ad * ratio : 0.0f;
+                const float g = dsur_dlogp * inv_m;
+#pragma unroll
+                for (int j = 0; j < JCAP; ++j)
+                    if (j * tpr < A) {
+                        const int o = fpart + tpr * j;
+                        const float m = mj[j], sg = sj[j];
+                        const float d = ca[j] - m;
+                        const float dm = g * (d / (sg * sg));
+                        if (o < A) {
+                            if (live) {
+                                L.dmu_d[row * A + o] = dm;
+                                L.dsigma_d[row * A + o] = g * ((d * d) / (sg * sg * sg) - 1.0f / sg) - L.entropy_coef * inv_m / sg;
+                            }
+                            sdy[frow * PA + o] = live ? dm : 0.0f;  // rows past M contribute nothing
+                        }
+                    }
+            } else if (fpart == 0) {
+                float g = 0.0f;
+                if (live) {
+                    const float inv_m = L.grad_scale / (float)M;
+                    const float v = acc[0], R = c0, clip = L.clip_param;
+                    float dv;
+                    if (L.use_clipped_value_loss) {
+                        const float vo = c1;
+                        const float dlt = v - vo;
+                        const float vc = vo + fminf(fmaxf(dlt, -clip), clip);
+                        const float l1v = (v - R) * (v - R), l2v = (vc - R) * (vc - R);
+                        if (l1v >= l2v) dv = 2.0f * (v - R);
+                        else dv = (dlt > -clip && dlt < clip) ? 2.0f * (vc - R) : 0.0f;
+                    } else {
+                        dv = -2.0f * (R - v);
+                    }
+                    g = L.value_loss_coef * dv * inv_m;
+                    L.dvalue_d[row] = g;
+                }
+                sdy[frow * PA] = g;
+            }
+        }
+        __syncthreads();
+        // ---- P2
+        float hv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hv[q] = m0 + acc_row(q, half) < M ? th[acc_row(q, half) * P + kc] : 0.0f;
+        f32x16 dx;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dx[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < AB * 16; ++s)
+            if (s < steps) {
+                const int o = 2 * s + half;
+                const float av = o < A ? sdy[r * PA + o] : 0.0f;
+                dx = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wreg[s], dx, 0, 0, 0);
+            }
+        if (m0 + 32 <= M) {  // interior block: unconditional stores
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float g = (ELU_IN && hv[q] <= 0.0f) ? hv[q] + alpha : 1.0f;  // ELU' from the activated value
+                dprev[(m0 + acc_row(q, half)) * (int64_t)K + kc] = dx[q] * g;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t row = m0 + acc_row(q, half);
+                const float g = (ELU_IN && hv[q] <= 0.0f) ? hv[q] + alpha : 1.0f;
+                if (row < M) dprev[row * (int64_t)K + kc] = dx[q] * g;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#pragma unroll
+            for (int b = 0; b < AB; ++b) {
+                const int o = 32 * b + r;
+                const float av = o < A ? sdy[acc_row(q, half) * PA + o] : 0.0f;
+                wacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[q], wacc[b], 0, 0, 0);
+                dbacc[b] += av;
+            }
+        }
+    }
+    float* p = part + (size_t)blockIdx.x * A * K;
+#pragma unroll
+    for (int b = 0; b < AB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int o = 32 * b + acc_row(q, half);
+            if (o < A) p[o * K + kc] = wacc[b][q];
+        }
+        if (kb == 0) {
+            const float tot = dbacc[b] + __shfl_xor(dbacc[b], 32);
+            if (half == 0 && 32 * b + r < A) part_db[(size_t)blockIdx.x * A + 32 * b + r] = tot;
+        }
+    }
+}
+
 int head_grid(int64_t M) { return (int)std::min<int64_t>((M + 31) / 32, 256); }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -698,9 +954,7 @@ extern "C" void imx_reduce_batch_destroy(imx_reduce_batch_t* b) {
 extern "C" int imx_reduce_batch_begin(imx_reduce_batch_t* b) {
     IMX_REQUIRE(b, "imx_reduce_batch_begin: null batch");
     IMX_REQUIRE(t_batch == nullptr, "imx_reduce_batch_begin: another batch is still open on this thread (flush it first)");
-    b->args.n = 0;
-    b->blocks = 0;
-    t_batch = b;
+    t_batch = b;  // (reductions queued on it directly -- imx_mlp_head_fwd_bwd -- stay: the batch empties at flush)
     return 0;
 }
 
@@ -709,6 +963,8 @@ extern "C" int imx_reduce_batch_flush(imx_reduce_batch_t* b, imx_stream_t stream
     t_batch = nullptr;
     if (b->args.n == 0) return 0;
     hipLaunchKernelGGL(k_mlp_reduce_batch, dim3(b->blocks), dim3(64, RED_Y), 0, (hipStream_t)stream, b->args);
+    b->args.n = 0;
+    b->blocks = 0;
     IMX_HIP(hipGetLastError());
     return 0;
 }
@@ -794,6 +1050,61 @@ extern "C" int imx_mlp_head_bwd(int64_t M, int K, int A, const float* dY_d, cons
                            has_activation, dprev_d, part, part_db);
     IMX_HIP(hipGetLastError());
     return reduce_or_defer("imx_mlp_head_bwd", (int64_t)A * K, G, part, dW_d, A, part_db, db_d, st);
+}
+
+extern "C" int imx_mlp_head_fwd_bwd(int64_t M, int K, int A, const float* z_d, int64_t ldz, const float* W_d, const float* b_d, float* y_d,
+                                    int elu_in, float elu_alpha, const imx_head_loss_t* loss, float* dprev_d, float* dW_d, float* db_d,
+                                    void* scratch_d, size_t scratch_bytes, imx_reduce_batch_t* defer_to, imx_stream_t stream) {
+    IMX_REQUIRE(M > 0 && z_d && W_d && b_d && y_d && loss && dprev_d && dW_d && db_d && scratch_d, "imx_mlp_head_fwd_bwd: bad arguments");
+    IMX_REQUIRE(A >= 1 && A <= HEAD_A, "imx_mlp_head_fwd_bwd: %d outputs (1..%d supported)", A, HEAD_A);
+    IMX_REQUIRE((K == 128 || K == 256) && ldz >= K && ldz % 4 == 0 && aligned16(z_d),
+                "imx_mlp_head_fwd_bwd: in-features %d (pitch %lld) must be 128 or 256 with 16-byte aligned rows", K, (long long)ldz);
+    IMX_REQUIRE(A <= 16, "imx_mlp_head_fwd_bwd: %d outputs (at most 16: wider heads run as imx_mlp_head_fwd_loss + imx_mlp_head_bwd)", A);
+    const imx_head_loss_t L = *loss;
+    IMX_REQUIRE(L.mode == 1 || L.mode == 2, "imx_mlp_head_fwd_bwd: loss mode %d (1 = policy, 2 = value)", L.mode);
+    if (L.mode == 1) {
+        IMX_REQUIRE(L.sigma_d && L.actions_d && L.old_logp_d && L.advantages_d && L.dmu_d && L.dsigma_d, "imx_mlp_head_fwd_bwd: null policy argument");
+        IMX_REQUIRE(L.sigma_stride == 0 || L.sigma_stride == A, "imx_mlp_head_fwd_bwd: sigma_stride must be 0 (shared std) or A");
+    } else {
+        IMX_REQUIRE(A == 1 && L.returns_d && L.dvalue_d && (!L.use_clipped_value_loss || L.old_values_d),
+                    "imx_mlp_head_fwd_bwd: value head needs A = 1, returns, old values");
+    }
+    const int G = head_grid(M);
+    const size_t need = ((size_t)G * A * K + (size_t)G * A) * sizeof(float);
+    IMX_REQUIRE(scratch_bytes >= need, "imx_mlp_head_fwd_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need);
+    float* part = (float*)scratch_d;
+    float* part_db = part + (size_t)G * A * K;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)((A * K + 3) & ~3) + 2ull * 32 * (K + 32) + 32ull * (A | 1) + 2 * HEAD_A) * sizeof(float);
+    const dim3 grid((unsigned)G), block((unsigned)(2 * K));
+#define IMX_HEAD_FUSED(K_, AM, LS, E)                                                                                                      \
+    do {                                                                                                                                  \
+        static bool attr = false;                                                                                                         \
+        if (!attr) {                                                                                                                      \
+            IMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fused<K_, AM, LS, E>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024));                                                                                    \
+            attr = true;                                                                                                                  \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((k_head_fused<K_, AM, LS, E>), grid, block, lds, st, M, A, z_d, ldz, W_d, b_d, elu_alpha, y_d, L, dprev_d, part, \
+                           part_db);                                                                                                      \
+    } while (0)
+#define IMX_HEAD_FUSED_K(AM, LS, E) do { if (K == 128) IMX_HEAD_FUSED(128, AM, LS, E); else IMX_HEAD_FUSED(256, AM, LS, E); } while (0)
+    if (L.mode == 2) {
+        if (elu_in) IMX_HEAD_FUSED_K(1, 2, true); else IMX_HEAD_FUSED_K(1, 2, false);
+    } else {
+        if (elu_in) IMX_HEAD_FUSED_K(16, 1, true); else IMX_HEAD_FUSED_K(16, 1, false);
+    }
+#undef IMX_HEAD_FUSED_K
+#undef IMX_HEAD_FUSED
+    IMX_HIP(hipGetLastError());
+    if (defer_to) {  // queue the reduction of the split partials on that batch (flushed by the backward pass that follows)
+        imx_reduce_batch* saved = t_batch;
+        t_batch = defer_to;
+        const int rc = reduce_or_defer("imx_mlp_head_fwd_bwd", (int64_t)A * K, G, part, dW_d, A, part_db, db_d, st);
+        t_batch = saved;
+        return rc;
+    }
+    return reduce_or_defer("imx_mlp_head_fwd_bwd", (int64_t)A * K, G, part, dW_d, A, part_db, db_d, st);
 }
 
 // ------------------------------------------------------------------------------------------- fused MLP inference (rollout)

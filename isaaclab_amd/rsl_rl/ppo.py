@@ -246,6 +246,19 @@ class DeferredReductions:
             pass
 
 
+def _head_bwd_args(scratch, which="a"):
+    """What ``mlp_forward`` needs to run the output layer's backward inside its forward launch (``imx_mlp_head_fwd_bwd``): that layer's
+    scratch and the reduce batch its partial sums are queued on; None = the split pair.  OFF by default: alone the one launch is faster
+    (38 vs 45 us policy head, 21 vs 31 us value head, tools/head_bench.py) but inside the update, next to the other network's kernels, it
+    measured slower (16.3 vs 16.15 ms; NOTES.md).  IMX_FUSED_HEAD=1 both heads, =a / =c the actor's / the critic's only."""
+    mode = os.getenv("IMX_FUSED_HEAD", "0")
+    if mode == "0" or (mode == "c" and which != "c") or (mode == "a" and which != "a"):
+        return None
+    if isinstance(scratch, DeferredReductions):
+        return {"scratch": scratch.scratch[-1], "batch": scratch.handle}
+    return {"scratch": scratch, "batch": None}
+
+
 def mlp_forward(layers, x, out=None, head_loss=None, first=None):
     """Returns (output, saved layer inputs).  Wide layers: library GEMM + bias epilogue, ELU in place on its output;
     the narrow output layer: ``imx_mlp_head_fwd`` (written into ``out`` when given).  ``head_loss`` = {"loss": ImxHeadLoss}:
@@ -265,7 +278,21 @@ def mlp_forward(layers, x, out=None, head_loss=None, first=None):
                 z = out
             else:
                 z = torch.empty(h.shape[0], lin.out_features, device=h.device, dtype=h.dtype)
-            if head_loss is not None and li == len(layers) - 1:
+            fb = head_loss.get("bwd") if head_loss is not None and li == len(layers) - 1 else None
+            if (fb is not None and lin.in_features in (128, 256) and lin.out_features <= 16 and h.stride(0) % 4 == 0
+                    and (pending_elu is not None or li == 0 or layers[li - 1][1] is None)):
+                # forward, loss gradient AND this layer's backward in one pass over the last hidden layer (imx_mlp_head_fwd_bwd): its
+                # activated values never travel to memory; the gradient handed to the layer below comes back as head_loss["dprev"]
+                scr = fb["scratch"]
+                dprev = torch.empty(h.shape[0], lin.in_features, device=h.device, dtype=h.dtype)
+                check(lib().imx_mlp_head_fwd_bwd(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0), lin.weight.data_ptr(),
+                                                 lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None), float(pending_elu or 0.0),
+                                                 ctypes.byref(head_loss["loss"]), dprev.data_ptr(), lin.weight.grad.data_ptr(),
+                                                 lin.bias.grad.data_ptr(), scr.data_ptr(), scr.numel(), fb.get("batch"),
+                                                 _lib.current_stream(h.device)))
+                head_loss["applied"] = True
+                head_loss["dprev"] = dprev
+            elif head_loss is not None and li == len(layers) - 1:
                 check(lib().imx_mlp_head_fwd_loss(h.shape[0], lin.in_features, lin.out_features, h.data_ptr(), h.stride(0),
                                                   lin.weight.data_ptr(), lin.bias.data_ptr(), z.data_ptr(), int(pending_elu is not None),
                                                   float(pending_elu or 0.0), ctypes.byref(head_loss["loss"]),
@@ -310,7 +337,7 @@ def mlp_forward(layers, x, out=None, head_loss=None, first=None):
     return h, saved
 
 
-def mlp_backward(layers, saved, dout, scratch=None):
+def mlp_backward(layers, saved, dout, scratch=None, head_dprev=None):
     """Writes dW/db of every layer straight into ``param.grad`` (views of the flat bucket).  dW / db: ``imx_mlp_dw``
     (split over the samples on the f32 MFMA); output layer: ``imx_mlp_head_bwd`` (dW, db, dX and the ELU' of the layer
     below in one pass); the wide dX GEMMs stay in the library, and the ELU backward of a hidden layer is folded into that
@@ -324,16 +351,19 @@ def mlp_backward(layers, saved, dout, scratch=None):
     if deferred is not None:
         check(L.imx_reduce_batch_begin(deferred.handle))
     try:
-        _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream)
+        _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream, head_dprev)
     finally:
         if deferred is not None:
             check(L.imx_reduce_batch_flush(deferred.handle, stream))
 
 
-def _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream):
+def _mlp_backward_layers(L, layers, saved, dout, M, scratch, deferred, stream, head_dprev=None):
     d = dout          # gradient w.r.t. the pre-activation output of layer i ...
     pending = None    # ... or (gradient w.r.t. its ELU output, that output, alpha): resolved inside imx_mlp_dw_elu
-    for i in range(len(layers) - 1, -1, -1):
+    top = len(layers) - 1
+    if head_dprev is not None:  # the output layer's backward already ran inside imx_mlp_head_fwd_bwd (mlp_forward)
+        d, top = head_dprev, top - 1
+    for i in range(top, -1, -1):
         lin, _ = layers[i]
         x = saved[i] if not isinstance(saved[i], tuple) else saved[i][1]
         prev_act = layers[i - 1][1] if i > 0 else None
@@ -624,6 +654,8 @@ class PPO:
         clipf, vclip = float(self.clip_param), int(self.use_clipped_value_loss)
         vcoef, ecoef = float(self.value_loss_coef), float(self.entropy_coef)
 
+        heads = {"a": None, "c": None}  # gradient below the output layer when imx_mlp_head_fwd_bwd already ran its backward
+
         def actor_pass(st):
             nonlocal sigma
             hl = None
@@ -632,7 +664,10 @@ class PPO:
                                                entropy_coef=ecoef, grad_scale=1.0, sigma_d=sigma.data_ptr(), actions_d=actions.data_ptr(),
                                                old_logp_d=old_logp.data_ptr(), advantages_d=advantages.data_ptr(),
                                                dmu_d=ws["dmu"].data_ptr(), dsigma_d=ws["dsigma"].data_ptr())}
+            if hl is not None:
+                hl["bwd"] = _head_bwd_args(ws["mlp_a"], "a")
             mu, saved_a = mlp_forward(self._actor_layers, obs, head_loss=hl, first=first_a)
+            heads["a"] = hl.get("dprev") if hl is not None else None
             if sigma is None:
                 sigma = torch.exp(pol.log_std).expand_as(mu).contiguous()
             if hl is None or not hl.get("applied"):
@@ -645,7 +680,9 @@ class PPO:
             hl = {"loss": _lib.ImxHeadLoss(mode=2, sigma_stride=0, use_clipped_value_loss=vclip, clip_param=clipf, value_loss_coef=vcoef,
                                            entropy_coef=ecoef, grad_scale=1.0, returns_d=returns.data_ptr(),
                                            old_values_d=target_values.data_ptr(), dvalue_d=ws["dvalue"].data_ptr())}
+            hl["bwd"] = _head_bwd_args(ws["mlp_c"], "c")
             value, saved_c = mlp_forward(self._critic_layers, critic_obs, head_loss=hl, first=first_c)
+            heads["c"] = hl.get("dprev")
             if not hl.get("applied"):
                 check(L.imx_ppo_loss_bwd(M, A, None, None, sstride, None, None, None, returns.data_ptr(), value.data_ptr(),
                                          target_values.data_ptr(), clipf, vclip, vcoef, ecoef, 1.0, None, None, ws["dvalue"].data_ptr(), st))
@@ -710,9 +747,9 @@ class PPO:
             if not loss_on_side:
                 aux.wait_stream(main)
                 aux.wait_event(value_ready)
-            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"], head_dprev=heads["a"])
             with torch.cuda.stream(side):
-                mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
+                mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"], head_dprev=heads["c"])
                 if loss_on_side:
                     side.wait_event(mu_ready)
                     loss_values(mu, value, side.cuda_stream)
@@ -734,8 +771,8 @@ class PPO:
             mu, saved_a = actor_pass(stream)
             value, saved_c = critic_pass(stream)
             loss_values(mu, value, stream)
-            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"])
-            mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"])
+            mlp_backward(self._actor_layers, saved_a, ws["dmu"], ws["mlp_a"], head_dprev=heads["a"])
+            mlp_backward(self._critic_layers, saved_c, ws["dvalue"], ws["mlp_c"], head_dprev=heads["c"])
         return self._out8
 
     update_graph = False  # set by the runner (use_graph=True): the update may run as one hipGraph replay, see update()

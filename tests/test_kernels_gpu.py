@@ -379,6 +379,67 @@ def test_mlp_head_matches_autograd(libimx, M, K, A):
     assert libimx.imx_mlp_head_fwd(M, K, 65, h.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), 0, 0.0, st) != 0
 
 
+@pytest.mark.parametrize("M,K,A,elu_in", [(24576, 128, 12, 1), (3001, 128, 1, 1), (77, 256, 16, 1), (1000, 128, 5, 0), (40, 256, 1, 0), (5000, 128, 13, 1)])
+def test_head_forward_loss_backward_in_one_launch_matches_the_split_pair(libimx, M, K, A, elu_in):
+    """imx_mlp_head_fwd_bwd (ELU on the way in, outputs, loss gradient, dprev, dW, db in one pass) against imx_mlp_head_fwd_loss +
+    imx_mlp_head_bwd: outputs / loss gradients to 1e-6 relative (the dot products are summed in another order), the backward results to
+    the tolerance of test_mlp_head_matches_autograd; z is left untouched; the reduction lands on the batch it was deferred to."""
+    from isaaclab_amd import _lib
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + K + A)
+    z = torch.randn(M, K, generator=g).cuda()
+    W, b = (0.1 * torch.randn(A, K, generator=g)).cuda(), (0.1 * torch.randn(A, generator=g)).cuda()
+    sigma = (0.5 + torch.rand(A, generator=g)).cuda()
+    act = torch.randn(M, A, generator=g).cuda()
+    old_logp = (-1.0 - torch.rand(M, generator=g) * A).cuda()
+    adv, ret, old_v = torch.randn(M, generator=g).cuda(), torch.randn(M, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+    st = _lib.current_stream(z.device)
+
+    def loss(dmu, dsg, dv):
+        if A > 1:
+            return _lib.ImxHeadLoss(mode=1, sigma_stride=0, use_clipped_value_loss=1, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.005,
+                                    grad_scale=1.0, sigma_d=sigma.data_ptr(), actions_d=act.data_ptr(), old_logp_d=old_logp.data_ptr(),
+                                    advantages_d=adv.data_ptr(), dmu_d=dmu.data_ptr(), dsigma_d=dsg.data_ptr())
+        return _lib.ImxHeadLoss(mode=2, sigma_stride=0, use_clipped_value_loss=1, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.005,
+                                grad_scale=1.0, returns_d=ret.data_ptr(), old_values_d=old_v.data_ptr(), dvalue_d=dv.data_ptr())
+
+    nbytes = int(L.imx_mlp_scratch_bytes(M, A, K))
+    res = []
+    for fused in (False, True):
+        zz, y = z.clone(), torch.empty(M, A, device="cuda")
+        dmu, dsg, dv = torch.zeros(M, A, device="cuda"), torch.zeros(M, A, device="cuda"), torch.zeros(M, 1, device="cuda")
+        dprev, dW, db = torch.empty(M, K, device="cuda"), torch.full((A, K), float("nan"), device="cuda"), torch.full((A,), float("nan"), device="cuda")
+        scr = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        hl = loss(dmu, dsg, dv)
+        if fused:
+            h = ctypes.c_void_p()
+            _lib.check(L.imx_reduce_batch_create(ctypes.byref(h)))
+            _lib.check(L.imx_mlp_head_fwd_bwd(M, K, A, zz.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), elu_in, 1.0, ctypes.byref(hl),
+                                              dprev.data_ptr(), dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nbytes, h, st))
+            torch.cuda.synchronize()
+            assert torch.equal(zz, z) and bool(torch.isnan(dW).all())  # input untouched; reduction still queued
+            _lib.check(L.imx_reduce_batch_begin(h))
+            _lib.check(L.imx_reduce_batch_flush(h, st))
+            L.imx_reduce_batch_destroy(h)
+        else:
+            _lib.check(L.imx_mlp_head_fwd_loss(M, K, A, zz.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), elu_in, 1.0, ctypes.byref(hl), st))
+            _lib.check(L.imx_mlp_head_bwd(M, K, A, (dmu if A > 1 else dv).data_ptr(), zz.data_ptr(), K, W.data_ptr(), 1.0, elu_in, dprev.data_ptr(),
+                                          dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nbytes, st))
+        torch.cuda.synchronize()
+        res.append((y, dmu, dsg, dv, dprev, dW, db))
+    (y0, dmu0, dsg0, dv0, dp0, dW0, db0), (y1, dmu1, dsg1, dv1, dp1, dW1, db1) = res
+    rel = lambda a_, b_: float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-30)
+    assert rel(y1, y0) <= 2e-6
+    if A > 1:
+        assert rel(dmu1, dmu0) <= 2e-5 and rel(dsg1, dsg0) <= 2e-5
+    else:
+        assert rel(dv1, dv0) <= 2e-5
+    assert rel(dp1, dp0) <= 2e-5 and rel(dW1, dW0) <= 2e-5 and rel(db1, db0) <= 2e-5
+    assert L.imx_mlp_head_fwd_bwd(M, 96, A, z.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), elu_in, 1.0, ctypes.byref(hl),
+                                  dprev.data_ptr(), dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nbytes, None, st) != 0  # K must be 128 or 256
+
+
 @pytest.mark.parametrize("fused_norm", [False, True])
 def test_adam_update_matches_torch_adam_and_adaptive_lr(libimx, fused_norm):
     """imx_adam_update (norm supplied) and imx_adam_update_norm (norm reduced in-kernel, last-block schedule) against
