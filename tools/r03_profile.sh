@@ -28,6 +28,7 @@ python tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch_size.txt
 python tools/pmc_summary.py $O/pmc_write > $O/pmc_write_size.txt
 python tools/pmc_traffic_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null
 for t in Isaac-Velocity-Flat-Anymal-C-v0 Isaac-Velocity-Rough-G1-v0 Isaac-Cartpole-v0; do python3 bench.py --task $t --no-cpu-baseline --no-large-n > $O/bench_$t.json.log 2> $O/bench_$t.err; echo "$t rc=$?"; done
+for t in Isaac-Velocity-Flat-Anymal-C-v0 Isaac-Velocity-Rough-G1-v0; do python3 bench.py --task $t --full-step --steps 5 --no-cpu-baseline --no-large-n > $O/bench_full_step_$t.json.log 2> $O/bench_full_step_$t.err; echo "full-step $t rc=$?"; done
 IMX_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-large-n > $O/bench_forced_dist_rccl.json.log 2> $O/bench_forced.err; echo "forced rc=$?"
 IMX_REHEARSE_ONE_GPU=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-large-n > $O/bench_rehearsal_2ranks_gloo.json.log 2> $O/bench_rehearsal.err; echo "rehearsal rc=$?"
 rm -rf $O/prof_bench $O/prof_full $O/pstep4096 $O/pstep65536 $O/pmc_fetch $O/pmc_write
