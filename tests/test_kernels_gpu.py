@@ -564,30 +564,41 @@ def test_rollout_post_bootstrap_and_episode_stats(libimx):
     assert_close(cur_r, (cr0 + rew) * (~d), 1e-6, "running reward") and assert_close(cur_l, (cl0 + 1) * (~d), 0, "running length") is None
 
 
-def test_whole_update_matches_torch_reference(libimx):
+@pytest.mark.parametrize("Dc,hidden,fused_head,tol", [(0, [64, 32], "0", 2e-5), (53, [64, 32], "0", 2e-5), (0, [256, 128], "1", 1e-4),
+                                                      (41, [128, 128], "1", 1e-4), (41, [128, 128], "0", 1e-4)])
+def test_whole_update_matches_torch_reference(libimx, monkeypatch, Dc, hidden, fused_head, tol):
     """PPO.update end to end (minibatch gather, both MLPs forward/backward on the HIP kernels, loss, grad-norm clip, adaptive
     KL learning rate, Adam, 2 epochs x 3 minibatches) against the same algorithm written with torch autograd, torch.optim.Adam
-    and the rsl_rl restatement (oracle/rsl_rl_oracle.py) on identical data and the identical minibatch permutation."""
+    and the rsl_rl restatement (oracle/rsl_rl_oracle.py) on identical data and the identical minibatch permutation.
+    Cases: shared observations (the stacked first layer in one imx_mlp_fwd_elu launch) and a privileged critic group (Dc > 0: each
+    network's first layer through imx_mlp_fwd_elu on its own stream); the split output-layer pair and imx_mlp_head_fwd_bwd.
+    Tolerance on the parameters after six Adam steps: 2e-5 for the narrow networks; 1e-4 (a tenth of ONE learning-rate step) for the
+    128-wide hidden layers, where Adam's g / (sqrt(v) + eps) turns the rounding noise of a near-zero gradient element into a visible
+    step -- the split pair and the fused head differ from torch by the same 1e-5 .. 5e-5 there."""
     import copy
 
     from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
     from isaaclab_amd.rsl_rl.ppo import PPO
     from oracle.rsl_rl_oracle import adaptive_lr, ppo_losses
 
+    monkeypatch.setenv("IMX_FUSED_HEAD", fused_head)
     T, N, D, A = 6, 50, 37, 5
     torch.manual_seed(11)
-    pol = ActorCritic(D, D, A, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32], init_noise_std=0.8)
+    pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8)
     ref_pol = copy.deepcopy(pol).cuda()
     kw = dict(num_learning_epochs=2, num_mini_batches=3, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
               max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
     alg = PPO(pol, device="cuda:0", **kw)
-    alg.init_storage("rl", N, T, (D,), (0,), (A,))  # no privileged observations: the critic sees the policy observations
+    alg.init_storage("rl", N, T, (D,), (Dc,), (A,))  # Dc = 0: no privileged observations, the critic sees the policy observations
     st = alg.storage
     g = torch.Generator().manual_seed(5)
     st.observations.copy_(torch.randn(T, N, D, generator=g))
+    if Dc:
+        st.privileged_observations.copy_(torch.randn(T, N, Dc, generator=g))
+    cobs_all = st.privileged_observations if Dc else st.observations
     with torch.no_grad():
         mu = ref_pol.actor(st.observations.flatten(0, 1)).view(T, N, A)
-        val = ref_pol.critic(st.observations.flatten(0, 1)).view(T, N, 1)
+        val = ref_pol.critic(cobs_all.flatten(0, 1)).view(T, N, 1)
     sigma = ref_pol.std.detach().expand(T, N, A).contiguous()
     act = mu + sigma * torch.randn(T, N, A, generator=g).cuda()
     st.mu.copy_(mu); st.sigma.copy_(sigma); st.actions.copy_(act); st.values.copy_(val)
@@ -596,7 +607,7 @@ def test_whole_update_matches_torch_reference(libimx):
     st.advantages.copy_(torch.randn(T, N, 1, generator=g))
     st.step = T
     flat = lambda x: x.flatten(0, 1)  # noqa: E731
-    data = [flat(x).clone() for x in (st.observations, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob, st.mu, st.sigma)]
+    data = [flat(x).clone() for x in (st.observations, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob, st.mu, st.sigma, cobs_all)]
 
     # ---- product path
     torch.manual_seed(99)  # seeds the randperm of the minibatch generator
@@ -612,9 +623,9 @@ def test_whole_update_matches_torch_reference(libimx):
     for _ in range(kw["num_learning_epochs"]):
         for i in range(kw["num_mini_batches"]):
             idx = perm[i * M:(i + 1) * M]
-            obs, a_, v_old, adv, ret, logp_old, mu_old, sg_old = (x[idx] for x in data)
+            obs, a_, v_old, adv, ret, logp_old, mu_old, sg_old, cobs = (x[idx] for x in data)
             mu_b = ref_pol.actor(obs)
-            s, v, e, kl = ppo_losses(mu_b, ref_pol.std.expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(obs), v_old,
+            s, v, e, kl = ppo_losses(mu_b, ref_pol.std.expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(cobs), v_old,
                                      kw["clip_param"], True)
             lr = adaptive_lr(lr, float(kl), kw["desired_kl"])
             for gr in opt.param_groups:
@@ -627,7 +638,7 @@ def test_whole_update_matches_torch_reference(libimx):
     assert abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr), (alg.learning_rate, lr)
     for (name, p), q in zip(pol.named_parameters(), ref_pol.parameters()):
         err = float((p - q).abs().max())
-        assert err <= 2e-5 * max(1.0, float(q.abs().max())), f"{name}: max err {err:.2e} after {kw['num_learning_epochs'] * kw['num_mini_batches']} optimiser steps"
+        assert err <= tol * max(1.0, float(q.abs().max())), f"{name}: max err {err:.2e} after {kw['num_learning_epochs'] * kw['num_mini_batches']} optimiser steps"
     stats = alg.loss_dict()
     assert all(np.isfinite(x) for x in stats.values())
 
