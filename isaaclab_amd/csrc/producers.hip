@@ -642,6 +642,129 @@ k_actuator_net_lstm_lanes(int64_t n, int num_lstm, int act, int num_weights, con
     }
 }
 
+// The same shapes on the matrix core: a wave owns 32 samples and forms the 32 gate pre-activations of a layer as
+//   G^T (32 gates x 32 samples) = W (32 x k) . [x ; h]^T (k x 32 samples),   v_mfma_f32_32x32x2_f32, one step per pair of inputs.
+// Two choices make everything after the MFMAs lane-local (no shuffle, no LDS traffic per sample):
+//   * gate rows are ORDERED so that accumulator register q of lane-half hf is gate type q >> 2 of hidden unit 4 hf + (q & 3): lane
+//     (sample, hf) ends up with i, f, g, o of units 4 hf .. 4 hf + 3 of ITS sample -- the cell update is 4 independent scalars per lane,
+//     and the state it needs / writes is one float4 of the (layers, n, 8) tensors;
+//   * the reduction index is PAIRED as (unit j, unit 4 + j) per step, so the lane half that owns units 4 hf .. supplies exactly its own
+//     new hidden values as the B operand of the next layer.
+// Weights: every lane keeps the A-operand values of its gate row in registers (13 per layer pair of the ANYdrive net) plus 16 bias sums.
+// 8 lanes per sample (k_actuator_net_lstm_lanes) spent its time in 128 LDS-fed multiply-adds and 32 shuffles per lane and layer: 13.7 us;
+// here a layer is 5 or 8 MFMAs per 32 samples.  Summation order differs from torch's (pairs of inputs per step): <= 1e-6 relative.
+typedef float prod_f32x16 __attribute__((ext_vector_type(16)));
+
+// sigmoid / tanh through v_exp_f32 and v_rcp_f32 (absolute error ~1e-7: inside the 1e-5 of the actuator tests; expf / tanhf are
+// 20-40 instructions each and a lane of the MFMA kernel evaluates 40 of them)
+IMX_DEV float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+IMX_DEV float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
+
+template <int D0>
+__global__ void __launch_bounds__(256)
+k_actuator_net_lstm_mfma(int64_t n, int num_lstm, int act, int num_weights, const float* __restrict__ weights, const float* __restrict__ q_des,
+                         const float* __restrict__ q, const float* __restrict__ qd, float* __restrict__ hid, float* __restrict__ cell,
+                         float saturation, const float* __restrict__ elim, const float* __restrict__ vlim, float* __restrict__ computed,
+                         float* __restrict__ applied) {
+    constexpr int H = 8, MAXL = 4;
+    extern __shared__ float s_w[];
+    const int lane = threadIdx.x & 63, r = lane & 31, hf = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + r;  // this lane's sample
+    const bool live = i0 < n;
+    const int64_t i = live ? i0 : n - 1;
+    // inputs and the state of EVERY layer are requested first, the weights copied to LDS behind them: one memory round trip for all of it
+    const float vel = qd[i];
+    const float perr = q_des[i] - q[i];
+    float4 hall[MAXL], call[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        const size_t at = ((size_t)(l < num_lstm ? l : 0) * n + i) * H + 4 * hf;
+        hall[l] = *reinterpret_cast<const float4*>(hid + at);
+        call[l] = *reinterpret_cast<const float4*>(cell + at);
+    }
+    for (int k = threadIdx.x; k < num_weights; k += blockDim.x) s_w[k] = weights[k];
+    __syncthreads();
+    // A-operand row of this lane: accumulator row rho = r  <->  gate type rho >> 3 of unit (rho & 3) + 4 ((rho >> 2) & 1)  ->  weight row
+    const int wr = (r >> 3) * H + (r & 3) + 4 * ((r >> 2) & 1);
+    float xin[4];
+    xin[0] = hf ? vel : perr;
+    xin[1] = xin[2] = xin[3] = 0.0f;
+    const float* __restrict__ w = s_w;
+    float hn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        if (l >= num_lstm) break;  // (uniform)
+        const int in_dim = l == 0 ? 2 : H;
+        const float* __restrict__ W_ih = w;
+        const float* __restrict__ W_hh = W_ih + 4 * H * in_dim;
+        const float* __restrict__ b_ih = W_hh + 4 * H * H;
+        const float* __restrict__ b_hh = b_ih + 4 * H;
+        const size_t at = ((size_t)l * n + i) * H + 4 * hf;
+        const float4 hv = hall[l], cv = call[l];
+        prod_f32x16 acc;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) acc[qq] = 0.0f;
+        if (l == 0) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W_ih[wr * 2 + hf], xin[0], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W_ih[wr * H + j + 4 * hf], xin[j], acc, 0, 0, 0);
+        }
+        const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W_hh[wr * H + j + 4 * hf], hvv[j], acc, 0, 0, 0);
+        const float cvv[4] = {cv.x, cv.y, cv.z, cv.w};
+        float cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int unit = 4 * hf + u;
+            const float gi = (acc[u] + b_ih[unit]) + b_hh[unit];
+            const float gf = (acc[4 + u] + b_ih[H + unit]) + b_hh[H + unit];
+            const float gg = (acc[8 + u] + b_ih[2 * H + unit]) + b_hh[2 * H + unit];
+            const float go = (acc[12 + u] + b_ih[3 * H + unit]) + b_hh[3 * H + unit];
+            cn[u] = fast_sigmoid(gf) * cvv[u] + fast_sigmoid(gi) * fast_tanh(gg);
+            hn[u] = fast_sigmoid(go) * fast_tanh(cn[u]);
+        }
+        if (live) {
+            *reinterpret_cast<float4*>(cell + at) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+            *reinterpret_cast<float4*>(hid + at) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xin[u] = hn[u];
+        w = b_hh + 4 * H;
+    }
+    // the head: H -> 1 (D0 == 0) or H -> D0 -> 1; each lane half sums over what it holds, one shuffle joins the halves
+    float part = 0.0f, bias_out;
+    if (D0 == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part += w[4 * hf + u] * hn[u];
+        bias_out = w[H];
+    } else {
+        constexpr int DD = D0 > 0 ? D0 : 32;
+        const float* __restrict__ b0 = w + DD * H;
+        const float* __restrict__ W1 = b0 + DD;
+        prod_f32x16 acc;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) acc[qq] = 0.0f;
+        const int rowd = r < DD ? r : 0;  // accumulator row rho = dense output rho (rows >= D0 multiply by zero)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r < DD ? w[rowd * H + j + 4 * hf] : 0.0f, hn[j], acc, 0, 0, 0);
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int rho = (qq & 3) + 8 * (qq >> 2) + 4 * hf;
+            if (rho < DD) part += W1[rho] * net_act(acc[qq] + b0[rho], act);
+        }
+        bias_out = W1[DD];
+    }
+    part += __shfl_xor(part, 32, 64);
+    const float out = part + bias_out;
+    if (live && hf == 0) {
+        computed[i] = out;
+        applied[i] = dc_motor_clip(out, vel, saturation, elim[i], vlim[i]);
+    }
+}
+
 // ActuatorNetMLP: the (N, history, J) queues of position error and velocity are rolled by one and topped up (:164-170); the inputs of
 // sample (env, joint) are the entries `input_idx` of both queues, scaled, position block first or second (:172-188).
 __global__ void __launch_bounds__(64)
@@ -714,7 +837,22 @@ extern "C" int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hid
     // the ANYdrive shapes run from registers (k_actuator_net_lstm_reg); anything else through the generic LDS kernel
     if (hidden == 8 && num_lstm <= 4 && (reinterpret_cast<uintptr_t>(hidden_state_d) & 15) == 0 && (reinterpret_cast<uintptr_t>(cell_state_d) & 15) == 0 &&
         ((num_dense == 1) || (num_dense == 2 && (dense_out_h[0] == 16 || dense_out_h[0] == 32)))) {
-        if (getenv("IMX_LSTM_KERNEL") == nullptr || getenv("IMX_LSTM_KERNEL")[0] != 'r') {  // default: eight lanes per sample
+        const char* which = getenv("IMX_LSTM_KERNEL");  // default: matrix core; "l": eight lanes per sample; "r": one lane per sample
+        if (which == nullptr || (which[0] != 'r' && which[0] != 'l')) {
+            const unsigned gm = (unsigned)((n + 127) / 128);  // 4 waves x 32 samples per workgroup
+            const size_t ldsm = (size_t)num_weights * sizeof(float);
+#define IMX_LSTM_MFMA(D0)                                                                                                                 \
+    hipLaunchKernelGGL((k_actuator_net_lstm_mfma<D0>), dim3(gm), dim3(256), ldsm, (hipStream_t)stream, n, num_lstm, act, (int)num_weights, \
+                       weights_d, joint_pos_target_d, joint_pos_d, joint_vel_d, hidden_state_d, cell_state_d, saturation_effort,         \
+                       effort_limit_d, velocity_limit_d, computed_effort_d, applied_effort_d)
+            if (num_dense == 1) IMX_LSTM_MFMA(0);
+            else if (dense_out_h[0] == 16) IMX_LSTM_MFMA(16);
+            else IMX_LSTM_MFMA(32);
+#undef IMX_LSTM_MFMA
+            IMX_HIP(hipGetLastError());
+            return 0;
+        }
+        if (which[0] != 'r') {  // eight lanes per sample
             const unsigned g8 = (unsigned)((n * 8 + 255) / 256);
             const size_t lds8 = (size_t)num_weights * sizeof(float);
 #define IMX_LSTM_LANES(D0)                                                                                                                \
