@@ -437,6 +437,7 @@ def time_mlp_dw(alg, M: int, device, launches: int = 30) -> dict:
     st = current_stream(device)
     flops = 0.0
     secs = 0.0
+    secs_k = 0.0
     shapes = []
     for lin, _ in alg._actor_layers:
         N, K = lin.out_features, lin.in_features
@@ -458,13 +459,34 @@ def time_mlp_dw(alg, M: int, device, launches: int = 30) -> dict:
         b.record()
         torch.cuda.synchronize(device)
         t = a.elapsed_time(b) * 1e-3 / launches
-        shapes.append({"out": N, "in": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12})
+        # ... and k_mlp_dw ALONE, as the update runs it: the reductions of a backward pass are deferred to one batched launch
+        # (imx_reduce_batch_*), so the events bracket eight launches whose reductions are only queued; the flush follows the end event
+        import ctypes
+
+        h = ctypes.c_void_p()
+        check(L.imx_reduce_batch_create(ctypes.byref(h)))
+        t_k = 0.0
+        for _ in range(4):
+            check(L.imx_reduce_batch_begin(h))
+            a.record()
+            for _ in range(8):
+                check(L.imx_mlp_dw(*args))
+            b.record()
+            check(L.imx_reduce_batch_flush(h, st))
+            torch.cuda.synchronize(device)
+            t_k += a.elapsed_time(b) * 1e-3 / 32
+        L.imx_reduce_batch_destroy(h)
+        shapes.append({"out": N, "in": K, "us": t * 1e6, "tflops": 2.0 * M * N * K / t / 1e12, "kernel_only_us": t_k * 1e6,
+                       "kernel_only_tflops": 2.0 * M * N * K / t_k / 1e12})
         flops += 2.0 * M * N * K
         secs += t
+        secs_k += t_k
     n = max(len(shapes), 1)
     return {"bound": "mfma", "kernel": "k_mlp_dw + k_mlp_reduce (imx_mlp_dw: dW = dY^T X, db; hidden layers of the actor, isolated launches)",
             "achieved": flops / secs / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / secs / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            "flops_per_launch": flops / n, "avg_launch_us": secs / n * 1e6, "samples": M, "per_layer": shapes}
+            "flops_per_launch": flops / n, "avg_launch_us": secs / n * 1e6, "samples": M, "per_layer": shapes,
+            "kernel_only": {"what": "k_mlp_dw without its reduction launch (deferred and batched in the update)", "achieved": flops / secs_k / 1e12,
+                            "frac": flops / secs_k / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": secs_k / n * 1e6}}
 
 
 def self_launch(n_gpus: int) -> int:

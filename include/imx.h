@@ -688,6 +688,9 @@ int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const
  * itself (W_d row-major with row pitch ldw >= in_features; packed_d 16-byte aligned; to be repeated whenever the weights change). */
 size_t imx_mlp_packed_floats(int out_features, int in_features);
 int imx_mlp_pack_weights(int out_features, int in_features, const float* W_d, int64_t ldw, float* packed_d, imx_stream_t stream);
+/* The same for up to 8 layers in ONE launch (HOST arrays of nlayers entries): the refresh after an optimiser step. */
+int imx_mlp_pack_weights_batch(int nlayers, const int* out_features, const int* in_features, const float* const* W_d, const int64_t* ldw,
+                               float* const* packed_d, imx_stream_t stream);
 
 /* First-layer forward of the update with the activation fused: Y (M,N; pitch ldy) = ELU(X W^T + b) (apply_elu = 0: no activation),
  * X (M,K; pitch ldx), W (N,K) dense row-major, K <= 256 (the observation width: 235, 48, 4 ...).  The layer is bound by WRITING its

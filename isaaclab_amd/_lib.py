@@ -169,6 +169,7 @@ _SIGNATURES = {
                                   POINTER(ImxPolicyAct), c_void_p]),
     "imx_mlp_packed_floats": (c_size_t, [c_int, c_int]),
     "imx_mlp_pack_weights": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "imx_mlp_pack_weights_batch": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imx_mlp_fwd_elu": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "imx_mlp_head_fwd_bwd": (c_int, [c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

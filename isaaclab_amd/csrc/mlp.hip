@@ -1534,10 +1534,24 @@ extern "C" int imx_mlp_infer(int64_t M, const float* X_d, int64_t ldx, int nnets
     return imx_mlp_infer_act(M, X_d, ldx, nnets, nlayers, dims, weights_d, weight_pitch, nullptr, biases_d, elu_alpha, out_d, nullptr, stream);
 }
 
-// one thread per float4 of the packed image
-__global__ void k_pack_weights(int N, int K, const float* __restrict__ W, int64_t ldw, float* __restrict__ out, int nsub, int64_t total4) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total4) return;
+// one thread per float4 of the packed images of up to 8 layers (one launch per refresh)
+constexpr int PACK_MAX = 8;
+struct PackArgs {
+    const float* W[PACK_MAX];
+    float* out[PACK_MAX];
+    int64_t ldw[PACK_MAX];
+    int64_t first4[PACK_MAX + 1];  // float4 offset of layer k in the launch's index space
+    int N[PACK_MAX], K[PACK_MAX], nsub[PACK_MAX];
+    int n;
+};
+__global__ void k_pack_weights(PackArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.first4[a.n]) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < PACK_MAX; ++q) k += (q < a.n && g >= a.first4[q]) ? 1 : 0;
+    const int64_t t = g - a.first4[k];
+    const int N = a.N[k], K = a.K[k], nsub = a.nsub[k];
     const int lane = (int)(t & 63);
     const int64_t chunk = t >> 6;
     const int i = (int)(chunk & 3), sc = (int)((chunk >> 2) % nsub), cb = (int)((chunk >> 2) / nsub);
@@ -1545,28 +1559,40 @@ __global__ void k_pack_weights(int N, int K, const float* __restrict__ W, int64_
     const int n = cb * 32 + r, k0 = 32 * sc + 16 * half + 4 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < N) {
-        const float* src = W + (size_t)n * ldw + k0;
+        const float* src = a.W[k] + (size_t)n * a.ldw[k] + k0;
         if (k0 + 0 < K) v.x = src[0];
         if (k0 + 1 < K) v.y = src[1];
         if (k0 + 2 < K) v.z = src[2];
         if (k0 + 3 < K) v.w = src[3];
     }
-    reinterpret_cast<float4*>(out)[t] = v;
+    reinterpret_cast<float4*>(a.out[k])[t] = v;
 }
 
 extern "C" size_t imx_mlp_packed_floats(int out_features, int in_features) {
     return (size_t)((out_features + 31) / 32 * 32) * (size_t)((in_features + 31) / 32 * 32);
 }
 
-extern "C" int imx_mlp_pack_weights(int out_features, int in_features, const float* W_d, int64_t ldw, float* packed_d, imx_stream_t stream) {
-    IMX_REQUIRE(out_features > 0 && in_features > 0 && W_d && packed_d && ldw >= in_features, "imx_mlp_pack_weights: bad arguments");
-    IMX_REQUIRE(aligned16(packed_d), "imx_mlp_pack_weights: the packed image must be 16-byte aligned");
-    const int nsub = (in_features + 31) / 32;
-    const int64_t total4 = (int64_t)imx_mlp_packed_floats(out_features, in_features) / 4;
-    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_features, in_features, W_d,
-                       ldw, packed_d, nsub, total4);
+extern "C" int imx_mlp_pack_weights_batch(int nlayers, const int* out_features, const int* in_features, const float* const* W_d,
+                                          const int64_t* ldw, float* const* packed_d, imx_stream_t stream) {
+    IMX_REQUIRE(nlayers >= 1 && nlayers <= PACK_MAX && out_features && in_features && W_d && ldw && packed_d,
+                "imx_mlp_pack_weights_batch: bad arguments (1..%d layers per call)", PACK_MAX);
+    PackArgs a{};
+    a.n = nlayers;
+    a.first4[0] = 0;
+    for (int k = 0; k < nlayers; ++k) {
+        IMX_REQUIRE(out_features[k] > 0 && in_features[k] > 0 && W_d[k] && packed_d[k] && ldw[k] >= in_features[k] && aligned16(packed_d[k]),
+                    "imx_mlp_pack_weights_batch: layer %d: bad shape, pitch or alignment", k);
+        a.W[k] = W_d[k]; a.out[k] = packed_d[k]; a.ldw[k] = ldw[k];
+        a.N[k] = out_features[k]; a.K[k] = in_features[k]; a.nsub[k] = (in_features[k] + 31) / 32;
+        a.first4[k + 1] = a.first4[k] + (int64_t)imx_mlp_packed_floats(out_features[k], in_features[k]) / 4;
+    }
+    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((a.first4[nlayers] + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     IMX_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int imx_mlp_pack_weights(int out_features, int in_features, const float* W_d, int64_t ldw, float* packed_d, imx_stream_t stream) {
+    return imx_mlp_pack_weights_batch(1, &out_features, &in_features, &W_d, &ldw, &packed_d, stream);
 }
 
 extern "C" int imx_mlp_infer_act(int64_t M, const float* X_d, int64_t ldx, int nnets, const int* nlayers, const int* dims,

@@ -171,6 +171,10 @@ class FusedInference:
         L = lib()
         self._packed = [torch.zeros(int(L.imx_mlp_packed_floats(w.shape[0], w.shape[1])), device=w.device, dtype=w.dtype) for w in ws]
         self._wpk = (ctypes.c_void_p * len(ws))(*[b.data_ptr() for b in self._packed]) if os.getenv("IMX_INFER_PACKED", "1") != "0" else None
+        nw = len(ws)
+        self._pack_args = (nw, (ctypes.c_int * nw)(*[w.shape[0] for w in ws]), (ctypes.c_int * nw)(*[w.shape[1] for w in ws]),
+                           (ctypes.c_void_p * nw)(*[w.data_ptr() for w in ws]), (ctypes.c_int64 * nw)(*[w.stride(0) for w in ws]),
+                           (ctypes.c_void_p * nw)(*[b.data_ptr() for b in self._packed]))
         self._keep = (ws, bs, wp)
         self._nl = (ctypes.c_int * len(nl))(*nl)
         self._dims = (ctypes.c_int * len(dims))(*dims)
@@ -187,10 +191,8 @@ class FusedInference:
         """Re-copy the padded weight buffers from the live parameters (capturable: plain device copies)."""
         for buf, w in self._padded:
             buf[:, :w.shape[1]].copy_(w)
-        if self._wpk is not None:
-            st = _lib.current_stream(self._packed[0].device)
-            for buf, w in zip(self._packed, self._keep[0]):
-                check(lib().imx_mlp_pack_weights(w.shape[0], w.shape[1], w.data_ptr(), w.stride(0), buf.data_ptr(), st))
+        if self._wpk is not None:  # all layers in one launch
+            check(lib().imx_mlp_pack_weights_batch(*self._pack_args, _lib.current_stream(self._packed[0].device)))
 
     def __call__(self, x: torch.Tensor, *outs: torch.Tensor, act=None):
         """``act``: an ``ImxPolicyAct`` -- the actor's workgroups then also sample the action, write the transition into the storage
