@@ -693,10 +693,12 @@ int imx_mlp_pack_weights_batch(int nlayers, const int* out_features, const int* 
                                float* const* packed_d, imx_stream_t stream);
 
 /* First-layer forward of the update with the activation fused: Y (M,N; pitch ldy) = ELU(X W^T + b) (apply_elu = 0: no activation),
- * X (M,K; pitch ldx), W (N,K) dense row-major, K <= 256 (the observation width: 235, 48, 4 ...).  The layer is bound by WRITING its
- * output (K is short); a library GEMM + a separate ELU pass writes, reads and writes it again.  Each wave keeps the weight rows of its 32
- * output columns in registers, the samples stream through LDS in tiles of 32 rows, bias + ELU are applied to the accumulators.  Exact fp32
- * (v_mfma_f32_32x32x2_f32, k ascending).  nn.Linear + nn.ELU of rsl_rl's ActorCritic MLPs (upstream rsl_rl/modules/actor_critic.py). */
+ * X (M,K; pitch ldx), W (N,K) dense row-major, K <= 256 (the observation width: 235, 48, 4 ...).  A library GEMM + a separate ELU pass
+ * writes, reads and writes the output again.  Each wave keeps the weight rows of its 32 output columns in registers, the samples stream
+ * through LDS in tiles of 32 rows (LDS DMA for K > 128 with 16-byte aligned rows), bias + ELU are applied to the accumulators.  fp32
+ * products accumulated in fp32 (v_mfma_f32_32x32x2_f32; inputs k and NS + k paired per step, NS = the kernel's step count: another
+ * summation order than a library GEMM's, same error class).  nn.Linear + nn.ELU of rsl_rl's ActorCritic MLPs (upstream
+ * rsl_rl/modules/actor_critic.py). */
 int imx_mlp_fwd_elu(int64_t M, int N, int K, const float* X_d, int64_t ldx, const float* W_d, const float* b_d, float elu_alpha,
                     int apply_elu, float* Y_d, int64_t ldy, imx_stream_t stream);
 
