@@ -837,7 +837,7 @@ extern "C" int imx_actuator_net_lstm(int64_t N, int64_t J, int num_lstm, int hid
     // the ANYdrive shapes run from registers (k_actuator_net_lstm_reg); anything else through the generic LDS kernel
     if (hidden == 8 && num_lstm <= 4 && (reinterpret_cast<uintptr_t>(hidden_state_d) & 15) == 0 && (reinterpret_cast<uintptr_t>(cell_state_d) & 15) == 0 &&
         ((num_dense == 1) || (num_dense == 2 && (dense_out_h[0] == 16 || dense_out_h[0] == 32)))) {
-        const char* which = getenv("IMX_LSTM_KERNEL");  // default: matrix core; "l": eight lanes per sample; "r": one lane per sample
+        static const char* const which = getenv("IMX_LSTM_KERNEL");  // read once.  default: matrix core; "l": eight lanes per sample; "r": one lane per sample
         if (which == nullptr || (which[0] != 'r' && which[0] != 'l')) {
             const unsigned gm = (unsigned)((n + 127) / 128);  // 4 waves x 32 samples per workgroup
             const size_t ldsm = (size_t)num_weights * sizeof(float);

@@ -215,10 +215,15 @@ def _is_head(lin: nn.Linear, x: torch.Tensor) -> bool:
 
 FUSED_FIRST_LAYER_MAX_K = 256  # imx_mlp_fwd_elu keeps a column's weights in registers
 
+# Measured alternatives that stay switchable (NOTES.md has the numbers); read ONCE, at import:
+FUSED_L0 = os.getenv("IMX_FUSED_L0", "1") != "0"        # first Linear + ELU as one imx_mlp_fwd_elu launch (off: library GEMM + ELU pass)
+FUSED_HEAD = os.getenv("IMX_FUSED_HEAD", "0")           # "1" / "a" / "c": output layer forward + loss + backward in one launch (slower in situ)
+LOSS_ON_SIDE = os.getenv("IMX_LOSS_ON_SIDE", "1") == "1"  # loss-value kernels behind the critic's backward pass (off: a third stream)
+
 
 def fused_first_layer_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous() and w.shape[1] == x.shape[1]
-            and x.shape[1] <= FUSED_FIRST_LAYER_MAX_K and os.getenv("IMX_FUSED_L0", "1") != "0")
+            and x.shape[1] <= FUSED_FIRST_LAYER_MAX_K and FUSED_L0)
 
 
 def mlp_scratch(layers, M: int, device) -> torch.Tensor:
@@ -253,7 +258,7 @@ def _head_bwd_args(scratch, which="a"):
     scratch and the reduce batch its partial sums are queued on; None = the split pair.  OFF by default: alone the one launch is faster
     (38 vs 45 us policy head, 21 vs 31 us value head, tools/head_bench.py) but inside the update, next to the other network's kernels, it
     measured slower (16.3 vs 16.15 ms; NOTES.md).  IMX_FUSED_HEAD=1 both heads, =a / =c the actor's / the critic's only."""
-    mode = os.getenv("IMX_FUSED_HEAD", "0")
+    mode = FUSED_HEAD
     if mode == "0" or (mode == "c" and which != "c") or (mode == "a" and which != "a"):
         return None
     if isinstance(scratch, DeferredReductions):
@@ -732,7 +737,7 @@ class PPO:
             # leave the other stream empty for the first 200 us of every minibatch.
             # the loss VALUES ride at the end of the critic's stream (its backward chain is the shorter one) rather than on a third
             # stream: one fork and one join fewer per minibatch, each a cross-queue release / acquire (16.28 -> 16.15 ms per update)
-            loss_on_side = os.getenv("IMX_LOSS_ON_SIDE", "1") == "1"
+            loss_on_side = LOSS_ON_SIDE
             aux = self._aux_stream()
             side.wait_stream(main)
             if joint_elu is not None:

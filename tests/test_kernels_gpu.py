@@ -581,7 +581,9 @@ def test_whole_update_matches_torch_reference(libimx, monkeypatch, Dc, hidden, f
     from isaaclab_amd.rsl_rl.ppo import PPO
     from oracle.rsl_rl_oracle import adaptive_lr, ppo_losses
 
-    monkeypatch.setenv("IMX_FUSED_HEAD", fused_head)
+    import isaaclab_amd.rsl_rl.ppo as ppo_mod
+
+    monkeypatch.setattr(ppo_mod, "FUSED_HEAD", fused_head)
     T, N, D, A = 6, 50, 37, 5
     torch.manual_seed(11)
     pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8)
