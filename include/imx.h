@@ -623,7 +623,8 @@ int imx_mlp_dw(int64_t M, int N, int K, const float* dY_d, int64_t ldy, const fl
 /* Deferred reductions: imx_mlp_dw / imx_mlp_dw_elu / imx_mlp_head_bwd end with a small kernel that sums their split partials
  * into dW / db.  Between imx_reduce_batch_begin(b) and imx_reduce_batch_flush(b, stream), calls issued from the SAME host
  * thread queue that step on `b` instead (at most 8) and flush launches one kernel for all of them: dW / db are only needed
- * by the optimiser, so the backward chain loses a 6 us launch per layer.  Every deferred call needs its OWN scratch. */
+ * by the optimiser, so the backward chain loses a 6 us launch per layer.  Every deferred call needs its OWN scratch.
+ * A batch empties at flush (not at begin): imx_mlp_head_fwd_bwd(..., defer_to = b, ...) may queue on it before it is opened. */
 typedef struct imx_reduce_batch imx_reduce_batch_t;
 int imx_reduce_batch_create(imx_reduce_batch_t** out);
 void imx_reduce_batch_destroy(imx_reduce_batch_t* batch);
