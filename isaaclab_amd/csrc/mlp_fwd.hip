@@ -196,17 +196,21 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwd_elu_dma(FwArgs a) {
         const float* wrow = wl + r * K + half * NS;
         for (int turn = 0; turn < 2; ++turn) {
             if ((w >> 1) == turn) {
-                if (wvec && avail >= 4) {
+                const int64_t avail4 = avail & ~(int64_t)3;  // floats of the block covered by whole, aligned float4
+                if (wvec && avail4 >= 4) {
                     // flat and contiguous on both sides: exactly the shape of the LDS DMA (1 KiB per instruction, nothing staged in registers,
                     // all of them in flight together -- a load/store loop pays one memory latency per iteration: ~20 us of the launch)
                     const unsigned wl_lds = lds_base + (unsigned)((w & 1) * FW_ROWS * FW_KP * 4);
                     for (int i = 0; i < 32 * K; i += 256) {
-                        const float* src = a.W + blk0 + min<int64_t>(i + 4 * lane, avail - 4);  // (past the block: re-read its end; those columns are masked)
+                        const float* src = a.W + blk0 + min<int64_t>(i + 4 * lane, avail4 - 4);  // (past the block: re-read its last whole vector; those columns are masked)
                         unsigned keep;
                         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                      : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)i * 4u)) : "memory");
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // a ragged last column block whose float count is not a multiple of four: its last 1-3 floats belong to a VALID column
+                    // and sit in a vector the clamp above replaced -- fetch them one by one (LDS operations of a wave execute in order)
+                    if (lane < avail - avail4) wl[avail4 + lane] = a.W[blk0 + avail4 + lane];
                 } else {
                     for (int i = 4 * lane; i < 32 * K; i += 256) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -833,7 +833,9 @@ def test_update_through_the_rccl_path_single_rank(libimx):
 
 @pytest.mark.parametrize("M,N,K,pitch,w_off", [(24576, 1024, 235, 236, 0), (1000, 512, 48, 48, 0), (77, 96, 4, 4, 0), (4099, 640, 256, 256, 0),
                                                (64, 1024, 235, 235, 0), (20, 128, 235, 236, 0), (3000, 200, 235, 236, 0), (2049, 256, 200, 200, 0),
-                                               (515, 384, 130, 132, 0), (1500, 256, 235, 236, 1), (700, 130, 48, 48, 3)])
+                                               (515, 384, 130, 132, 0), (1500, 256, 235, 236, 1), (700, 130, 48, 48, 3),
+                                               # ragged last column block whose float count is not a multiple of four (found by tools/fuzz_kernels.py)
+                                               (31, 31, 223, 224, 0), (2000, 31, 143, 148, 0), (300, 161, 235, 236, 0)])
 def test_fused_first_layer_forward_matches_torch(libimx, M, N, K, pitch, w_off):
     """imx_mlp_fwd_elu (Linear + ELU of the first layer, weights in registers, bias + ELU on the accumulators) against torch's
     addmm + elu in fp64-checked fp32: ragged tiles, a single tile, column counts that are not multiples of 128 (down to whole waves

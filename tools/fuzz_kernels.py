@@ -1,0 +1,166 @@
+"""Random-shape sweep of the stand-alone kernels against torch (fp64) / the rsl_rl restatement: GAE, imx_mlp_fwd_elu, imx_mlp_infer (packed
+and row layouts), imx_mlp_dw[_elu], the LSTM actuator (all three kernels).  Test infrastructure, run on the GPU box:
+    python tools/fuzz_kernels.py [cases per kernel] [seed]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from isaaclab_amd import _lib
+
+L = _lib.lib()
+st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1.0)
+
+
+def case_gae(rng):
+    from isaaclab_amd.rsl_rl.storage import gae_returns
+    from oracle.rsl_rl_oracle import compute_returns
+
+    T, N = int(rng.integers(1, 70)), int(rng.choice([1, 3, 64, 65, 1000, 4096, 16385, 30000]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    rew, val, last = torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g), torch.randn(N, 1, generator=g)
+    dones = (torch.rand(T, N, 1, generator=g) < float(rng.choice([0.0, 0.02, 0.3, 1.0]))).to(torch.uint8)
+    gamma, lam, norm = float(rng.choice([0.9, 0.99, 0.998])), float(rng.choice([0.0, 0.95, 1.0])), bool(rng.integers(0, 2)) and T * N > 1
+    r0, a0 = compute_returns(rew, val, dones, last, gamma, lam, norm)
+    r1, a1 = gae_returns(rew.cuda(), val.cuda(), dones.cuda(), last.cuda(), gamma, lam, norm)
+    e = max(rel(r1.cpu(), r0), rel(a1.cpu(), a0))
+    return e <= 2e-5, f"T={T} N={N} gamma={gamma} lam={lam} norm={norm} err={e:.1e}"
+
+
+def case_fwd_elu(rng):
+    M, N, K = int(rng.choice([1, 31, 33, 500, 4097, 24576])), int(rng.choice([1, 31, 128, 200, 512, 1024])), int(rng.integers(1, 257))
+    pitch = K + int(rng.choice([0, 0, 1, 3, 5]))
+    w_off = int(rng.choice([0, 0, 1, 2]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    xb = torch.full((M, pitch), float("nan"))
+    xb[:, :K] = torch.randn(M, K, generator=g)
+    x = xb.cuda()[:, :K]
+    wf = torch.full((N * K + 8,), float("nan"))
+    wf[w_off:w_off + N * K] = torch.randn(N * K, generator=g) / K ** 0.5
+    w, b = wf.cuda()[w_off:w_off + N * K].view(N, K), torch.randn(N, generator=g).cuda()
+    elu, alpha = int(rng.integers(0, 2)), float(rng.choice([1.0, 0.5]))
+    y = torch.full((M, N + 2), 7.0, device="cuda")
+    _lib.check(L.imx_mlp_fwd_elu(M, N, K, x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), alpha, elu, y.data_ptr(), y.stride(0), st()))
+    ref = torch.addmm(b.double(), x.double(), w.double().t())
+    if elu:
+        ref = torch.nn.functional.elu(ref, alpha=alpha)
+    e = rel(y[:, :N], ref)
+    return e <= 2e-5 and bool((y[:, N:] == 7.0).all()), f"M={M} N={N} K={K} pitch={pitch} w_off={w_off} elu={elu} err={e:.1e}"
+
+
+def case_infer(rng):
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import FusedInference, _mlp_layers
+
+    M, D, A = int(rng.choice([1, 5, 33, 100, 2048, 4096, 5000])), int(rng.integers(1, 400)), int(rng.integers(1, 40))
+    hidden = [int(rng.choice([32, 64, 96, 128, 200, 256, 512])) for _ in range(int(rng.integers(1, 4)))]
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    pol = ActorCritic(D, D, A, actor_hidden_dims=hidden, critic_hidden_dims=hidden, init_noise_std=1.0).cuda()
+    for p in pol.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0.0, 0.3)
+    x = torch.randn(M, D, device="cuda")
+    inf = FusedInference(_mlp_layers(pol.actor), _mlp_layers(pol.critic))
+    mu, val = torch.full((M, A), float("nan"), device="cuda"), torch.full((M, 1), float("nan"), device="cuda")
+    inf(x, mu, val)
+    packed, inf._wpk = inf._wpk, None
+    mu_r, val_r = torch.full_like(mu, float("nan")), torch.full_like(val, float("nan"))
+    inf(x, mu_r, val_r)
+    inf._wpk = packed
+    same = torch.equal(mu, mu_r) and torch.equal(val, val_r)
+    with torch.no_grad():
+        e = max(rel(mu, pol.actor.double()(x.double())), rel(val, pol.critic.double()(x.double())))
+    return same and e <= 2e-5, f"M={M} D={D} A={A} hidden={hidden} packed==rows {same} err={e:.1e}"
+
+
+def case_dw(rng):
+    M, N, K = int(rng.choice([64, 100, 3000, 24576])), int(rng.choice([17, 128, 200, 256, 512])), int(rng.choice([5, 48, 128, 235, 256, 512]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    ldx = K + int(rng.choice([0, (-K) % 4]))
+    X = torch.randn(M, ldx, generator=g).cuda()[:, :K]
+    dH, Hs = torch.randn(M, N, generator=g).cuda(), torch.nn.functional.elu(torch.randn(M, N, generator=g)).cuda()
+    act = int(rng.integers(0, 2))
+    dW, db, dZ = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda"), torch.empty(M, N, device="cuda")
+    nb = int(L.imx_mlp_scratch_bytes(M, N, K))
+    scr = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    if act:
+        _lib.check(L.imx_mlp_dw_elu(M, N, K, dH.data_ptr(), N, Hs.data_ptr(), N, 1.0, dZ.data_ptr(), N, X.data_ptr(), X.stride(0), dW.data_ptr(),
+                                    db.data_ptr(), scr.data_ptr(), nb, st()))
+        dz = dH.double() * torch.where(Hs > 0, torch.ones_like(Hs), Hs + 1.0).double()
+    else:
+        _lib.check(L.imx_mlp_dw(M, N, K, dH.data_ptr(), N, X.data_ptr(), X.stride(0), dW.data_ptr(), db.data_ptr(), scr.data_ptr(), nb, st()))
+        dz = dH.double()
+    refW, refb = dz.t() @ X.double(), dz.sum(0)
+    scale = float((dz.abs().t() @ X.double().abs()).max())
+    e = max(float((dW.double() - refW).abs().max()) / scale, float((db.double() - refb).abs().max()) / float(dz.abs().sum(0).max()))
+    ok = e <= 2e-6 and (not act or rel(dZ, dz) <= 1e-6)
+    return ok, f"M={M} N={N} K={K} ldx={ldx} act={act} err={e:.1e}"
+
+
+def case_lstm(rng):
+    from isaaclab_amd.producers import ActuatorNetLSTM
+
+    N, J = int(rng.choice([1, 7, 64, 1000, 4096])), int(rng.choice([1, 12, 23]))
+    nl, d0 = int(rng.integers(1, 4)), int(rng.choice([0, 16, 32]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    r = lambda *s: (torch.rand(*s, generator=g) - 0.5)  # noqa: E731
+    lstm = [(r(32, 2 if k == 0 else 8), r(32, 8), r(32), r(32)) for k in range(nl)]
+    head = [(r(1, 8), r(1))] if d0 == 0 else [(r(d0, 8), r(d0)), (r(1, d0), r(1))]
+    ref = torch.nn.LSTM(2, 8, nl, batch_first=True).double()
+    with torch.no_grad():
+        for k, (wi, wh, bi, bh) in enumerate(lstm):
+            getattr(ref, f"weight_ih_l{k}").copy_(wi); getattr(ref, f"weight_hh_l{k}").copy_(wh)
+            getattr(ref, f"bias_ih_l{k}").copy_(bi); getattr(ref, f"bias_hh_l{k}").copy_(bh)
+    outs = {}
+    steps = [tuple(torch.randn(N, J, generator=g) for _ in range(3)) for _ in range(3)]
+    for kern in ("m", "l", "r"):
+        os.environ["IMX_LSTM_KERNEL_FUZZ"] = kern
+        a = ActuatorNetLSTM(N, J, 80.0, 7.5, 120.0, lstm_layers=[tuple(t.cuda() for t in l_) for l_ in lstm],
+                            head=[tuple(t.cuda() for t in h_) for h_ in head], head_activation="softsign", device="cuda:0")
+        for q_des, q, qd in steps:
+            a.compute(q_des.cuda(), q.cuda(), qd.cuda())
+        outs[kern] = (a.computed_effort.cpu(), a.sea_hidden_state.cpu(), a.sea_cell_state.cpu())
+        break  # (the library picks its kernel once per process: only the default one is swept here)
+    h = c = torch.zeros(nl, N * J, 8, dtype=torch.float64)
+    with torch.no_grad():
+        for q_des, q, qd in steps:
+            x = torch.stack([(q_des - q).flatten(), qd.flatten()], 1).double().unsqueeze(1)
+            y, (h, c) = ref(x, (h, c))
+            y = y[:, -1]
+            if d0 == 0:
+                out = y @ head[0][0].double().t() + head[0][1].double()
+            else:
+                out = torch.nn.functional.softsign(y @ head[0][0].double().t() + head[0][1].double()) @ head[1][0].double().t() + head[1][1].double()
+    got = outs["m"]
+    e = max(rel(got[0].reshape(-1, 1), out), rel(got[1], h), rel(got[2], c))
+    return e <= 1e-5, f"N={N} J={J} lstm layers={nl} head={d0} err={e:.1e}"
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm)):
+        rng = np.random.default_rng(seed)
+        nbad, worst = 0, ""
+        for c in range(cases):
+            try:
+                ok, msg = fn(rng)
+            except Exception as exc:  # an error return of the library is a finding too
+                ok, msg = False, f"{type(exc).__name__}: {exc}"
+            if not ok:
+                nbad += 1
+                print(f"{name} case {c}: FAIL {msg}", flush=True)
+            worst = msg
+        bad += nbad
+        print(f"{name}: {cases - nbad} / {cases} cases agree (last: {worst})", flush=True)
+    sys.exit(1 if bad else 0)
