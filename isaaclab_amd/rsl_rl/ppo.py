@@ -653,6 +653,10 @@ class PPO:
         pol = self.policy
         stream = _lib.current_stream(self.device)
         M, A = actions.shape
+        for name, t in (("actions", actions), ("target_values", target_values), ("advantages", advantages), ("returns", returns),
+                        ("old_actions_log_prob", old_logp), ("old_mu", old_mu), ("old_sigma", old_sigma)):
+            if not t.is_contiguous():  # the loss kernels address these densely (observations alone may carry a row pitch)
+                raise _lib.ImxError(f"PPO.minibatch_step: {name} must be contiguous (shape {tuple(t.shape)}, strides {t.stride()})")
         ws = self._workspace(M, A)
         if pol.noise_std_type == "scalar":
             sigma, sstride = pol.std, 0

@@ -112,7 +112,11 @@ class RolloutStorage:
         if getattr(self, "_mb_key", None) != key:
             # wide rows (observations) start on 16-byte boundaries: the dW kernel of the first layer reads them with 16-byte loads
             # even when the width is ragged (235 -> pitch 236: 81.8 -> 71.2 us, tools/dw_pitch.py); the views keep the true width
-            pitch = [(s.shape[1] + 3) // 4 * 4 if s.shape[1] >= 16 else s.shape[1] for s in srcs]
+            # ONLY the observation arrays are padded: their consumers (GEMMs, imx_mlp_dw, imx_mlp_fwd_elu) take a row pitch; the per-sample
+            # arrays of width A (actions, old mu / sigma) go to kernels that address them densely -- padding them too fed the loss kernels
+            # wrong columns for every A >= 16 that is not a multiple of four (17, 18, 37: found by tools/fuzz_kernels.py in round 3)
+            n_obs = 2 if self.privileged_observations is not None else 1
+            pitch = [(s.shape[1] + 3) // 4 * 4 if (k < n_obs and s.shape[1] >= 16) else s.shape[1] for k, s in enumerate(srcs)]
             # ONE set of batch buffers PER MINIBATCH of the permutation: upstream draws the permutation once per update and walks the same
             # num_mini_batches index slices in every epoch, so each slice is gathered once (first epoch) and its buffers are reused in the
             # later epochs -- 4 gather launches per update instead of 20 (the whole storage once more in HBM: 108 MB at 4096 x 24)

@@ -564,9 +564,10 @@ def test_rollout_post_bootstrap_and_episode_stats(libimx):
     assert_close(cur_r, (cr0 + rew) * (~d), 1e-6, "running reward") and assert_close(cur_l, (cl0 + 1) * (~d), 0, "running length") is None
 
 
-@pytest.mark.parametrize("Dc,hidden,fused_head,tol", [(0, [64, 32], "0", 2e-5), (53, [64, 32], "0", 2e-5), (0, [256, 128], "1", 1e-4),
-                                                      (41, [128, 128], "1", 1e-4), (41, [128, 128], "0", 1e-4)])
-def test_whole_update_matches_torch_reference(libimx, monkeypatch, Dc, hidden, fused_head, tol):
+@pytest.mark.parametrize("Dc,hidden,fused_head,tol,A", [(0, [64, 32], "0", 2e-5, 5), (53, [64, 32], "0", 2e-5, 5), (0, [256, 128], "1", 1e-4, 5),
+                                                        (41, [128, 128], "1", 1e-4, 5), (41, [128, 128], "0", 1e-4, 5),
+                                                        (0, [64, 32], "0", 2e-5, 16), (0, [64, 32], "0", 2e-5, 17), (0, [64, 32], "0", 2e-5, 37)])
+def test_whole_update_matches_torch_reference(libimx, monkeypatch, Dc, hidden, fused_head, tol, A):
     """PPO.update end to end (minibatch gather, both MLPs forward/backward on the HIP kernels, loss, grad-norm clip, adaptive
     KL learning rate, Adam, 2 epochs x 3 minibatches) against the same algorithm written with torch autograd, torch.optim.Adam
     and the rsl_rl restatement (oracle/rsl_rl_oracle.py) on identical data and the identical minibatch permutation.
@@ -584,7 +585,7 @@ def test_whole_update_matches_torch_reference(libimx, monkeypatch, Dc, hidden, f
     import isaaclab_amd.rsl_rl.ppo as ppo_mod
 
     monkeypatch.setattr(ppo_mod, "FUSED_HEAD", fused_head)
-    T, N, D, A = 6, 50, 37, 5
+    T, N, D = 6, 50, 37
     torch.manual_seed(11)
     pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8)
     ref_pol = copy.deepcopy(pol).cuda()

@@ -1,5 +1,5 @@
 """Random-shape sweep of the stand-alone kernels against torch (fp64) / the rsl_rl restatement: GAE, imx_mlp_fwd_elu, imx_mlp_infer (packed
-and row layouts), imx_mlp_dw[_elu], the LSTM actuator (all three kernels).  Test infrastructure, run on the GPU box:
+and row layouts), imx_mlp_dw[_elu], the LSTM actuator, a whole PPO.update with random network shapes.  Test infrastructure, run on the GPU box:
     python tools/fuzz_kernels.py [cases per kernel] [seed]"""
 import ctypes
 import os
@@ -145,11 +145,84 @@ def case_lstm(rng):
     return e <= 1e-5, f"N={N} J={J} lstm layers={nl} head={d0} err={e:.1e}"
 
 
+def case_update(rng):
+    """A whole PPO.update against torch autograd + Adam (tests/test_kernels_gpu.py::test_whole_update_matches_torch_reference with the
+    network shapes, observation widths, batch and epoch counts drawn at random)."""
+    import copy
+
+    import isaaclab_amd.rsl_rl.ppo as ppo_mod
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+    from oracle.rsl_rl_oracle import adaptive_lr, ppo_losses
+
+    T, N = int(rng.integers(2, 9)), int(rng.choice([8, 50, 96, 400]))
+    D, A = int(rng.integers(3, 300)), int(rng.integers(1, 20))
+    Dc = int(rng.choice([0, 0, int(rng.integers(3, 300))]))
+    hidden = [int(rng.choice([32, 64, 128, 256])) for _ in range(int(rng.integers(1, 4)))]
+    nmb, nep = int(rng.choice([1, 2, 4])), int(rng.integers(1, 3))
+    while (T * N) % nmb:
+        nmb -= 1
+    ppo_mod.FUSED_HEAD = str(rng.choice(["0", "1"]))
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8)
+    ref_pol = copy.deepcopy(pol).cuda()
+    kw = dict(num_learning_epochs=nep, num_mini_batches=nmb, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
+              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    alg = PPO(pol, device="cuda:0", **kw)
+    alg.init_storage("rl", N, T, (D,), (Dc,), (A,))
+    stg = alg.storage
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    stg.observations.copy_(torch.randn(T, N, D, generator=g))
+    if Dc:
+        stg.privileged_observations.copy_(torch.randn(T, N, Dc, generator=g))
+    cobs_all = stg.privileged_observations if Dc else stg.observations
+    with torch.no_grad():
+        mu = ref_pol.actor(stg.observations.flatten(0, 1)).view(T, N, A)
+        val = ref_pol.critic(cobs_all.flatten(0, 1)).view(T, N, 1)
+    sigma = ref_pol.std.detach().expand(T, N, A).contiguous()
+    act = mu + sigma * torch.randn(T, N, A, generator=g).cuda()
+    stg.mu.copy_(mu); stg.sigma.copy_(sigma); stg.actions.copy_(act); stg.values.copy_(val)
+    stg.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+    stg.returns.copy_(val + 0.3 * torch.randn(T, N, 1, generator=g).cuda())
+    stg.advantages.copy_(torch.randn(T, N, 1, generator=g))
+    stg.step = T
+    flat = lambda x: x.flatten(0, 1)  # noqa: E731
+    data = [flat(x).clone() for x in (stg.observations, stg.actions, stg.values, stg.advantages, stg.returns, stg.actions_log_prob, stg.mu, stg.sigma, cobs_all)]
+    seed = int(rng.integers(0, 1 << 30))
+    torch.manual_seed(seed)
+    alg.update()
+    torch.cuda.synchronize()
+    torch.manual_seed(seed)
+    Mb = T * N // nmb
+    perm = torch.randperm(nmb * Mb, device="cuda:0")
+    opt = torch.optim.Adam(ref_pol.parameters(), lr=kw["learning_rate"])
+    lr = kw["learning_rate"]
+    for _ in range(nep):
+        for i in range(nmb):
+            idx = perm[i * Mb:(i + 1) * Mb]
+            obs, a_, v_old, adv, ret, logp_old, mu_old, sg_old, cobs = (x[idx] for x in data)
+            mu_b = ref_pol.actor(obs)
+            s_, v_, e_, kl = ppo_losses(mu_b, ref_pol.std.expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(cobs), v_old, 0.2, True)
+            lr = adaptive_lr(lr, float(kl.detach()), 0.01)
+            for gr in opt.param_groups:
+                gr["lr"] = lr
+            loss = s_ + v_ - 0.005 * e_
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref_pol.parameters(), 1.0)
+            opt.step()
+    err = max(float((p - q).abs().max()) / max(1.0, float(q.abs().max())) for p, q in zip(pol.parameters(), ref_pol.parameters()))
+    lr_ok = abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr)
+    # (half a learning-rate step per optimiser step taken: on its first steps Adam moves a parameter by lr * g / (|g| + 1e-8), which turns the
+    #  rounding of a gradient element of magnitude ~1e-8 into a visible fraction of lr; real defects measured 2e-3 .. 2e-2 here)
+    return lr_ok and err <= 5e-4 * nep * nmb, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} lr_ok={lr_ok} err={err:.1e}"
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
-    for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm)):
+    for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm), ("update", case_update)):
         rng = np.random.default_rng(seed)
         nbad, worst = 0, ""
         for c in range(cases):
