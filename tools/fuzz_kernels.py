@@ -145,6 +145,70 @@ def case_lstm(rng):
     return e <= 1e-5, f"N={N} J={J} lstm layers={nl} head={d0} err={e:.1e}"
 
 
+def case_infer_act(rng):
+    """imx_mlp_infer_act (PPO.act in the actor head's epilogue) against imx_mlp_infer + imx_policy_act: same seed and step counter ->
+    bit-identical actions, log-probs, means, sigmas and stored observations; the critic's values identical too."""
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import FusedInference, _mlp_layers
+
+    M, D, A = int(rng.choice([1, 33, 100, 2048, 4096, 5000])), int(rng.integers(1, 400)), int(rng.integers(1, 41))
+    hidden = [int(rng.choice([32, 64, 128, 256, 512])) for _ in range(int(rng.integers(1, 4)))]
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    pol = ActorCritic(D, D, A, actor_hidden_dims=hidden, critic_hidden_dims=hidden, init_noise_std=float(rng.choice([0.3, 1.0]))).cuda()
+    x = torch.randn(M, D, device="cuda")
+    inf = FusedInference(_mlp_layers(pol.actor), _mlp_layers(pol.critic))
+    seed, step = int(rng.integers(0, 1 << 40)), torch.tensor([int(rng.integers(0, 100000))], dtype=torch.int32, device="cuda")
+    mu, val = torch.empty(M, A, device="cuda"), torch.empty(M, 1, device="cuda")
+    inf(x, mu, val)
+    ref = [torch.full((M, A), float("nan"), device="cuda") for _ in range(3)] + [torch.full((M,), float("nan"), device="cuda"),
+                                                                                 torch.full((M, 1), float("nan"), device="cuda"), torch.full((M, D), float("nan"), device="cuda")]
+    a0, m0, s0, lp0, v0, o0 = ref
+    _lib.check(L.imx_policy_act(M, A, D, mu.data_ptr(), pol.std.data_ptr(), val.data_ptr(), x.data_ptr(), seed, step.data_ptr(), a0.data_ptr(),
+                                lp0.data_ptr(), m0.data_ptr(), s0.data_ptr(), v0.data_ptr(), o0.data_ptr(), None, st()))
+    a1, m1, s1, lp1, o1 = (torch.full_like(t, float("nan")) for t in (a0, m0, s0, lp0, o0))
+    val1 = torch.full_like(val, float("nan"))
+    act = _lib.ImxPolicyAct(std_d=pol.std.data_ptr(), seed=seed, step_counter_d=step.data_ptr(), actions_out_d=a1.data_ptr(), logp_out_d=lp1.data_ptr(),
+                            mu_out_d=m1.data_ptr(), sigma_out_d=s1.data_ptr(), obs_out_d=o1.data_ptr(), plan=None, state=None, buf=None, pre_clip=float("inf"))
+    inf(x, None, val1, act=act)
+    torch.cuda.synchronize()
+    same = all(torch.equal(p, q) for p, q in ((a0, a1), (m0, m1), (s0, s1), (lp0, lp1), (o0, o1), (val, val1)))
+    return same and bool(torch.isfinite(a1).all()), f"M={M} D={D} A={A} hidden={hidden} identical={same}"
+
+
+def case_ppo_loss(rng):
+    """imx_ppo_loss_fwd / imx_ppo_loss_bwd against the restatement's ppo_losses + autograd (shared and per-sample sigma)."""
+    from oracle.rsl_rl_oracle import ppo_losses
+
+    M, A = int(rng.choice([1, 7, 256, 257, 3000, 24576])), int(rng.integers(1, 41))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    per_sample = bool(rng.integers(0, 2))
+    mu = torch.randn(M, A, generator=g).cuda().double().requires_grad_(True)
+    sg = ((0.3 + torch.rand(M, A, generator=g)) if per_sample else (0.3 + torch.rand(A, generator=g)).expand(M, A).contiguous()).cuda().double().requires_grad_(True)
+    val = torch.randn(M, 1, generator=g).cuda().double().requires_grad_(True)
+    act, old_mu = torch.randn(M, A, generator=g).cuda(), torch.randn(M, A, generator=g).cuda()
+    old_sg = (0.3 + torch.rand(M, A, generator=g)).cuda()
+    old_logp = (-1.0 - torch.rand(M, 1, generator=g) * A).cuda()
+    adv, ret, old_v = (torch.randn(M, 1, generator=g).cuda() for _ in range(3))
+    clip, vcoef, ecoef, clipped = 0.2, float(rng.choice([1.0, 0.5])), float(rng.choice([0.0, 0.01])), int(rng.integers(0, 2))
+    s_, v_, e_, kl = ppo_losses(mu, sg, act.double(), old_logp.double(), old_mu.double(), old_sg.double(), adv.double(), ret.double(), val, old_v.double(),
+                                clip, bool(clipped))
+    loss = s_ + vcoef * v_ - ecoef * e_
+    loss.backward()
+    mu32, sg32, val32 = mu.detach().float(), sg.detach().float(), val.detach().float()
+    out8 = torch.empty(8, device="cuda")
+    scr = torch.empty(int(L.imx_ppo_scratch_bytes(M)), dtype=torch.uint8, device="cuda")
+    _lib.check(L.imx_ppo_loss_fwd(M, A, mu32.data_ptr(), sg32.data_ptr(), A, act.data_ptr(), old_logp.data_ptr(), old_mu.data_ptr(), old_sg.data_ptr(),
+                                  adv.data_ptr(), ret.data_ptr(), val32.data_ptr(), old_v.data_ptr(), clip, clipped, vcoef, ecoef, out8.data_ptr(), None,
+                                  scr.data_ptr(), st()))
+    dmu, dsg, dv = torch.empty(M, A, device="cuda"), torch.empty(M, A, device="cuda"), torch.empty(M, 1, device="cuda")
+    _lib.check(L.imx_ppo_loss_bwd(M, A, mu32.data_ptr(), sg32.data_ptr(), A, act.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                  val32.data_ptr(), old_v.data_ptr(), clip, clipped, vcoef, ecoef, 1.0, dmu.data_ptr(), dsg.data_ptr(), dv.data_ptr(), st()))
+    refs = torch.stack([s_, v_, e_, kl, loss]).detach()
+    e = max(rel(out8[:5], refs), rel(dmu, mu.grad), rel(dsg, sg.grad), rel(dv, val.grad))
+    # (fp32 kernel against an fp64 reference of an exp() of a sum of A terms: 1e-4 relative on the largest entry)
+    return e <= 1e-4, f"M={M} A={A} per_sample_sigma={per_sample} clipped={clipped} err={e:.1e}"
+
+
 def case_update(rng):
     """A whole PPO.update against torch autograd + Adam (tests/test_kernels_gpu.py::test_whole_update_matches_torch_reference with the
     network shapes, observation widths, batch and epoch counts drawn at random)."""
@@ -222,7 +286,8 @@ if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
-    for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm), ("update", case_update)):
+    for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm), ("infer_act", case_infer_act), ("ppo_loss", case_ppo_loss),
+                     ("update", case_update)):
         rng = np.random.default_rng(seed)
         nbad, worst = 0, ""
         for c in range(cases):
