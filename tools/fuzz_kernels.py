@@ -275,11 +275,22 @@ def case_update(rng):
             loss.backward()
             torch.nn.utils.clip_grad_norm_(ref_pol.parameters(), 1.0)
             opt.step()
-    err = max(float((p - q).abs().max()) / max(1.0, float(q.abs().max())) for p, q in zip(pol.parameters(), ref_pol.parameters()))
+    # Per parameter tensor: every element within 1e-4, except for a handful (<= 2 + 1e-4 of the tensor) that may be off by up to the
+    # learning-rate steps taken -- on its first steps Adam moves a parameter by lr * g / (|g| + 1e-8) whatever |g| is, so the rounding
+    # of a gradient element of magnitude ~1e-8 flips a visible fraction of lr (seen: 1 element of 25 856 off by 1.07e-3).  The defects
+    # this sweep found moved EVERY element by 2e-3 .. 2e-2.
+    err, outliers_ok = 0.0, True
+    for (name, p), q in zip(pol.named_parameters(), ref_pol.parameters()):
+        d = (p.detach() - q.detach()).abs()
+        over = d > 1e-4
+        n_over = int(over.sum())
+        if n_over > 2 + int(1e-4 * d.numel()) or float(d.max()) > 2.5e-3 * nep * nmb:
+            outliers_ok = False
+        err = max(err, float(d[~over].max()) if n_over < d.numel() else float(d.max()))
+        if os.getenv("FUZZ_VERBOSE"):
+            print(f"      {name}: max |diff| {float(d.max()):.2e}, elements over 1e-4: {n_over} of {d.numel()}")
     lr_ok = abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr)
-    # (half a learning-rate step per optimiser step taken: on its first steps Adam moves a parameter by lr * g / (|g| + 1e-8), which turns the
-    #  rounding of a gradient element of magnitude ~1e-8 into a visible fraction of lr; real defects measured 2e-3 .. 2e-2 here)
-    return lr_ok and err <= 5e-4 * nep * nmb, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} lr_ok={lr_ok} err={err:.1e}"
+    return lr_ok and outliers_ok and err <= 1e-4, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} lr_ok={lr_ok} err={err:.1e}"
 
 
 if __name__ == "__main__":
