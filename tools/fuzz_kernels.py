@@ -227,11 +227,17 @@ def case_update(rng):
     while (T * N) % nmb:
         nmb -= 1
     ppo_mod.FUSED_HEAD = str(rng.choice(["0", "1"]))
+    std_type = str(rng.choice(["scalar", "scalar", "log"]))
+    schedule, clipped_v = str(rng.choice(["adaptive", "adaptive", "fixed"])), bool(rng.choice([True, True, False]))
+    norm_mb, two_streams = bool(rng.choice([False, False, True])), bool(rng.choice([True, True, False]))
+    ecoef, vcoef, gnorm = float(rng.choice([0.005, 0.0])), float(rng.choice([1.0, 0.5])), float(rng.choice([1.0, 0.3]))
     torch.manual_seed(int(rng.integers(0, 1 << 30)))
-    pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8)
+    pol = ActorCritic(D, Dc or D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=0.8, noise_std_type=std_type)
     ref_pol = copy.deepcopy(pol).cuda()
-    kw = dict(num_learning_epochs=nep, num_mini_batches=nmb, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
-              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    ref_std = (lambda: ref_pol.std) if std_type == "scalar" else (lambda: torch.exp(ref_pol.log_std))
+    kw = dict(num_learning_epochs=nep, num_mini_batches=nmb, schedule=schedule, desired_kl=0.01, learning_rate=1e-3, entropy_coef=ecoef,
+              max_grad_norm=gnorm, clip_param=0.2, value_loss_coef=vcoef, use_clipped_value_loss=clipped_v,
+              normalize_advantage_per_mini_batch=norm_mb, two_streams=two_streams)
     alg = PPO(pol, device="cuda:0", **kw)
     alg.init_storage("rl", N, T, (D,), (Dc,), (A,))
     stg = alg.storage
@@ -243,7 +249,7 @@ def case_update(rng):
     with torch.no_grad():
         mu = ref_pol.actor(stg.observations.flatten(0, 1)).view(T, N, A)
         val = ref_pol.critic(cobs_all.flatten(0, 1)).view(T, N, 1)
-    sigma = ref_pol.std.detach().expand(T, N, A).contiguous()
+    sigma = ref_std().detach().expand(T, N, A).contiguous()
     act = mu + sigma * torch.randn(T, N, A, generator=g).cuda()
     stg.mu.copy_(mu); stg.sigma.copy_(sigma); stg.actions.copy_(act); stg.values.copy_(val)
     stg.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
@@ -265,15 +271,18 @@ def case_update(rng):
         for i in range(nmb):
             idx = perm[i * Mb:(i + 1) * Mb]
             obs, a_, v_old, adv, ret, logp_old, mu_old, sg_old, cobs = (x[idx] for x in data)
+            if norm_mb:  # upstream: advantages normalised per minibatch (mean / unbiased std + 1e-8)
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
             mu_b = ref_pol.actor(obs)
-            s_, v_, e_, kl = ppo_losses(mu_b, ref_pol.std.expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(cobs), v_old, 0.2, True)
-            lr = adaptive_lr(lr, float(kl.detach()), 0.01)
+            s_, v_, e_, kl = ppo_losses(mu_b, ref_std().expand_as(mu_b), a_, logp_old, mu_old, sg_old, adv, ret, ref_pol.critic(cobs), v_old, 0.2, clipped_v)
+            if schedule == "adaptive":
+                lr = adaptive_lr(lr, float(kl.detach()), 0.01)
             for gr in opt.param_groups:
                 gr["lr"] = lr
-            loss = s_ + v_ - 0.005 * e_
+            loss = s_ + vcoef * v_ - ecoef * e_
             opt.zero_grad()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(ref_pol.parameters(), 1.0)
+            torch.nn.utils.clip_grad_norm_(ref_pol.parameters(), gnorm)
             opt.step()
     # Per parameter tensor: every element within 1e-4, except for a handful (<= 2 + 1e-4 of the tensor) that may be off by up to the
     # learning-rate steps taken -- on its first steps Adam moves a parameter by lr * g / (|g| + 1e-8) whatever |g| is, so the rounding
@@ -284,13 +293,13 @@ def case_update(rng):
         d = (p.detach() - q.detach()).abs()
         over = d > 1e-4
         n_over = int(over.sum())
-        if n_over > 2 + int(1e-4 * d.numel()) or float(d.max()) > 2.5e-3 * nep * nmb:
+        if n_over > 2 + int(1e-4 * d.numel()) or float(d.max()) > 2.5e-3 * nep * nmb:  # (lr = 1e-3; the adaptive schedule can raise it 1.5x per step)
             outliers_ok = False
         err = max(err, float(d[~over].max()) if n_over < d.numel() else float(d.max()))
         if os.getenv("FUZZ_VERBOSE"):
             print(f"      {name}: max |diff| {float(d.max()):.2e}, elements over 1e-4: {n_over} of {d.numel()}")
     lr_ok = abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr)
-    return lr_ok and outliers_ok and err <= 1e-4, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} lr_ok={lr_ok} err={err:.1e}"
+    return lr_ok and outliers_ok and err <= 1e-4, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} std={std_type} {schedule} clipped_v={clipped_v} norm_mb={norm_mb} two_streams={two_streams} lr_ok={lr_ok} err={err:.1e}"
 
 
 if __name__ == "__main__":
