@@ -183,3 +183,22 @@ def test_seed_is_callable_on_the_class_like_the_reference_staticmethod():
     a = torch.rand(3)
     assert ManagerBasedRLEnv.seed(42) == 42
     assert torch.equal(a, torch.rand(3))
+
+
+def test_only_observation_minibatch_buffers_carry_a_row_pitch():
+    """The minibatch buffers of the update: observation rows start on 16-byte boundaries (their consumers -- GEMMs, imx_mlp_dw,
+    imx_mlp_fwd_elu -- take a row pitch), every per-sample array (actions, old mu / sigma, values ...) is dense: the loss kernels index
+    them as (M, A) without a pitch.  Padding those too (round 2 until the end of round 3) fed the update wrong columns for action counts
+    >= 16 that are not a multiple of four (G1: 37)."""
+    from isaaclab_amd.rsl_rl.storage import RolloutStorage
+
+    for D, Dc, A in ((310, 0, 37), (235, 187, 17), (48, 0, 12), (37, 53, 18)):
+        st = RolloutStorage(8, 4, (D,), (Dc,), (A,), device="cpu")
+        st._minibatch_setup(2)
+        n_obs = 2 if Dc else 1
+        for dst in st._mb_dst_sets:
+            for k, buf in enumerate(dst):
+                if k < n_obs and buf.shape[1] >= 16:
+                    assert buf.stride(0) % 4 == 0 and buf.stride(0) - buf.shape[1] < 4, (D, Dc, A, k, buf.stride())
+                else:
+                    assert buf.is_contiguous(), (D, Dc, A, k, tuple(buf.shape), buf.stride())
