@@ -85,11 +85,54 @@ def case_command(rng):
     return f"N={N} step_dt={step_dt} resample={cfg['resampling_time_range']} heading={cfg['heading_command']} steps={steps}"
 
 
+def case_pd_actuator(rng):
+    from isaaclab_amd.producers import PDActuator
+    from oracle.producers_oracle import actuator_pd
+
+    N, J = int(rng.choice([1, 7, 64, 1000, 4096])), int(rng.choice([1, 2, 12, 23, 37]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    r = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    stiff, damp, elim, vlim = 20 + 80 * r(N, J), 0.5 + 4 * r(N, J), 20 + 60 * r(N, J), 2 + 8 * r(N, J)
+    sat = float(rng.choice([60.0, 120.0]))
+    q_des, q, qd, qd_des, ff = (torch.randn(N, J, generator=g) * float(rng.choice([0.3, 2.0])) for _ in range(5))
+    dc = bool(rng.integers(0, 2))
+    kw = dict(velocity_limit=vlim, saturation_effort=sat) if dc else {}
+    c0, a0 = actuator_pd(q_des, qd_des, ff, q, qd, stiff, damp, elim, **kw)
+    act = PDActuator(stiff.cuda(), damp.cuda(), elim.cuda(), **({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}))
+    applied = act.compute(q_des.cuda(), q.cuda(), qd.cuda(), qd_des.cuda(), ff.cuda())
+    assert_close(act.computed_effort, c0, 1e-5, "computed effort")
+    assert_close(applied, a0, 1e-5, "applied effort")
+    return f"N={N} J={J} dc_motor={dc}"
+
+
+def case_articulation(rng):
+    from isaaclab_amd.producers import ArticulationRootState
+    from oracle.mdp_oracle import convert_quat
+
+    N, J, dt = int(rng.choice([1, 63, 1000, 4096])), int(rng.choice([1, 12, 37])), float(rng.choice([0.005, 0.02]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    prev = torch.randn(N, J, generator=g)
+    st = ArticulationRootState(N, J, "cuda:0", prev.cuda())
+    sim_t, acc_t = 0.0, -1.0
+    for k in range(int(rng.integers(2, 6))):
+        tf = torch.cat([torch.randn(N, 3, generator=g), torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1)], 1)
+        vel, dv = torch.randn(N, 6, generator=g), torch.randn(N, J, generator=g)
+        sim_t += dt
+        elapsed, acc_t = sim_t - acc_t, sim_t
+        st.update(tf.cuda(), vel.cuda(), dv.cuda(), dt)
+        assert torch.equal(st.root_pos_w.cpu(), tf[:, :3]) and torch.equal(st.root_quat_w.cpu(), convert_quat(tf[:, 3:7], to="wxyz")), (k, "root pose")
+        assert torch.equal(st.root_lin_vel_w.cpu(), vel[:, :3]) and torch.equal(st.root_ang_vel_w.cpu(), vel[:, 3:]), (k, "root velocity")
+        assert_close(st.joint_acc, (dv - prev) / elapsed, 1e-5, "joint_acc")
+        prev = dv.clone()
+    return f"N={N} J={J} dt={dt}"
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
-    for name, fn in (("contact_sensor", case_contact), ("velocity_command", case_command)):
+    for name, fn in (("contact_sensor", case_contact), ("velocity_command", case_command), ("pd_actuator", case_pd_actuator),
+                     ("articulation", case_articulation)):
         rng = np.random.default_rng(seed)
         nbad, last = 0, ""
         for c in range(cases):
