@@ -50,3 +50,10 @@ def test_producer_sweep(kind):
     rng = np.random.default_rng(31)
     for _ in range(8):
         getattr(fp, "case_" + kind)(rng)
+
+
+@pytest.mark.parametrize("seed", [300, 301, 302])
+def test_orchestration_sweep(seed):
+    import fuzz_orchestration
+
+    fuzz_orchestration.one_case(seed)
