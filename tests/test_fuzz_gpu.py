@@ -57,3 +57,10 @@ def test_orchestration_sweep(seed):
     import fuzz_orchestration
 
     fuzz_orchestration.one_case(seed)
+
+
+@pytest.mark.parametrize("seed", [400, 401, 402])
+def test_raycast_sweep(seed):
+    import fuzz_raycast
+
+    fuzz_raycast.one_case(seed)
