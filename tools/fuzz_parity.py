@@ -57,6 +57,16 @@ def one_case(case_seed: int) -> str:
         cpu_feed.advance()
         if rough:
             orc.ray_hits_w = env._ray_hits.cpu()
+            # the fused ray path of the observation kernel against the fp64 brute force over all triangles (a slice of the envs)
+            from oracle.mdp_oracle import quat_apply_yaw
+            from oracle.raycast import raycast_f64
+
+            ne, R = min(64, N), env.plan.num_rays
+            local = torch.from_numpy(env.plan.ray_starts_local).unsqueeze(0).repeat(ne, 1, 1)
+            starts = quat_apply_yaw(cpu_feed["root_quat_w"][:ne].repeat(1, R), local) + cpu_feed["root_pos_w"][:ne].unsqueeze(1)
+            dirs = torch.tensor(env.plan.ray_direction).repeat(ne * R, 1)
+            h64, _, _ = raycast_f64(terrain[0], terrain[1], starts.reshape(-1, 3).numpy(), dirs.numpy())
+            assert_close(orc.ray_hits_w[:ne].reshape(-1, 3), torch.from_numpy(h64), FLOAT_TOL, "ray hits vs fp64 brute force")
         out = orc.post_physics_step(u)
         assert torch.equal(term.cpu(), out["terminated"]) and torch.equal(tout.cpu(), out["time_outs"]), "masks"
         assert torch.equal(env.reset_env_ids.cpu(), out["reset_env_ids"]), "reset ids"
