@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("kind", ["gae", "fwd_elu", "infer", "dw", "lstm", "infer_act", "ppo_loss", "update"])
+@pytest.mark.parametrize("kind", ["gae", "fwd_elu", "infer", "dw", "lstm", "infer_act", "ppo_loss", "update", "update_graph"])
 def test_kernel_sweep(libimx, kind):
     import fuzz_kernels as fk
 

@@ -302,12 +302,67 @@ def case_update(rng):
     return lr_ok and outliers_ok and err <= 1e-4, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} std={std_type} {schedule} clipped_v={clipped_v} norm_mb={norm_mb} two_streams={two_streams} lr_ok={lr_ok} err={err:.1e}"
 
 
+def case_update_graph(rng):
+    """PPO.update captured as one hipGraph against the eager update (tests/test_kernels_gpu.py::test_update_graph_replay_equals_eager_update
+    with random shapes): parameters, Adam state, learning rate and logged losses identical to the last bit over six updates."""
+    import copy
+
+    import isaaclab_amd.rsl_rl.ppo as ppo_mod
+    from isaaclab_amd.rsl_rl.actor_critic import ActorCritic
+    from isaaclab_amd.rsl_rl.ppo import PPO
+
+    T, N = int(rng.integers(2, 9)), int(rng.choice([16, 96, 400]))
+    D, A = int(rng.integers(3, 300)), int(rng.integers(1, 41))
+    hidden = [int(rng.choice([32, 64, 128, 256])) for _ in range(int(rng.integers(1, 4)))]
+    nmb, nep = int(rng.choice([1, 2, 4])), int(rng.integers(1, 3))
+    while (T * N) % nmb:
+        nmb -= 1
+    ppo_mod.FUSED_HEAD = "0"
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    pol0 = ActorCritic(D, D, A, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden), init_noise_std=1.0)
+    kw = dict(num_learning_epochs=nep, num_mini_batches=nmb, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.005,
+              max_grad_norm=1.0, clip_param=0.2, value_loss_coef=1.0, use_clipped_value_loss=True)
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    obs, noise = torch.randn(T, N, D, generator=g), torch.randn(T, N, A, generator=g)
+    ret_noise, adv = 0.3 * torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
+    seed = int(rng.integers(0, 1 << 30))
+    results = []
+    for graph in (False, True):
+        alg = PPO(copy.deepcopy(pol0), device="cuda:0", **kw)
+        alg.update_graph = graph
+        alg.init_storage("rl", N, T, (D,), (0,), (A,))
+        torch.manual_seed(seed)
+        stats = []
+        for it in range(6):
+            if graph and it == 4:
+                alg._update_t = "graph"
+            stg = alg.storage
+            stg.observations.copy_(obs + 0.1 * it)
+            with torch.no_grad():
+                mu = alg.policy.actor(stg.observations.flatten(0, 1)).view(T, N, A)
+                val = alg.policy.critic(stg.observations.flatten(0, 1)).view(T, N, 1)
+            sigma = alg.policy.std.detach().expand(T, N, A).contiguous()
+            act = mu + sigma * noise.cuda()
+            stg.mu.copy_(mu); stg.sigma.copy_(sigma); stg.actions.copy_(act); stg.values.copy_(val)
+            stg.actions_log_prob.copy_(torch.distributions.Normal(mu, sigma).log_prob(act).sum(-1, keepdim=True))
+            stg.returns.copy_(val + ret_noise.cuda())
+            stg.advantages.copy_(adv)
+            stg.step = T
+            alg.update()
+            stats.append(alg.loss_dict())
+        torch.cuda.synchronize()
+        results.append((alg.bucket.flat.clone(), alg.bucket.exp_avg.clone(), alg.bucket.exp_avg_sq.clone(), alg.learning_rate, stats))
+    (p0, m0, v0, lr0, s0), (p1, m1, v1, lr1, s1) = results
+    same = lr0 == lr1 and s0 == s1 and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    return same and bool(torch.isfinite(p1).all()), f"T={T} N={N} D={D} A={A} hidden={hidden} mb={nmb} ep={nep} identical={same}"
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
     for name, fn in (("gae", case_gae), ("fwd_elu", case_fwd_elu), ("infer", case_infer), ("dw", case_dw), ("lstm", case_lstm), ("infer_act", case_infer_act), ("ppo_loss", case_ppo_loss),
-                     ("update", case_update)):
+                     ("update", case_update), ("update_graph", case_update_graph)):
         rng = np.random.default_rng(seed)
         nbad, worst = 0, ""
         for c in range(cases):
