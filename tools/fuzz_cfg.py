@@ -2,7 +2,7 @@
 Anymal-C scene with random subsets (order kept) of the reward / termination / observation terms of the kitchen-sink fixture (every mdp
 term the path knows, two observation groups), random weights (incl. 0), scale / clip / uniform, gaussian and constant noise (add, scale, abs), modifier chains (scale, bias, clip,
 DigitalFilter, Integrator), per-term and
-per-group history, episode length, action scale / clip.  Masks / ids bit-exact, floats 1e-5.  Test infrastructure, run on
+per-group history, episode length, the six joint action classes in random combinations (processed actions compared).  Masks / ids bit-exact, floats 1e-5.  Test infrastructure, run on
 the GPU box:  python tools/fuzz_cfg.py [cases] [first_seed]"""
 import copy
 import json
@@ -26,6 +26,7 @@ CFG = os.path.join(ROOT, "isaaclab_amd", "configs")
 BASE = json.load(open(os.path.join(CFG, "Isaac-Velocity-Rough-Anymal-C-v0.json")))
 POOL = json.load(open(os.path.join(CFG, "Isaac-Velocity-Rough-Anymal-C-v0-kitchen.json")))["env"]
 NOISE = "isaaclab.utils.noise.noise_model:uniform_noise"
+ACTIONS = json.load(open(os.path.join(CFG, "Isaac-Velocity-Flat-Anymal-C-v0-actions.json")))["env"]["actions"]
 
 
 def mutate(rng):
@@ -106,10 +107,28 @@ def mutate(rng):
     env["episode_length_s"] = float(rng.choice([20.0, 5.0, 0.5]))
     # (decimation stays: with a shorter env step the height scanner's update_period gates its refresh -- SensorBase, reproduced by the
     #  product and pinned by the kitchen fixture -- while this harness hands the oracle every step's hits)
-    act = env["actions"]["joint_pos"]
-    act["scale"] = float(rng.choice([0.5, 0.25, 1.0]))
-    if rng.random() < 0.3:
-        act["clip"] = {".*": [-1.0, 1.0]}
+    if rng.random() < 0.6:
+        act = env["actions"]["joint_pos"]
+        act["scale"] = float(rng.choice([0.5, 0.25, 1.0]))
+        if rng.random() < 0.3:
+            act["clip"] = {".*": [-1.0, 1.0]}
+        what.append("JointPositionAction")
+    else:  # a random combination of the other joint action classes (the `-actions` fixture's terms with other numbers)
+        pool = copy.deepcopy(ACTIONS)
+        keep_a = [n for n in pool if rng.random() < 0.6] or ["all_ema"]
+        env["actions"] = {}
+        for n in keep_a:
+            a = pool[n]
+            if isinstance(a.get("scale"), float):
+                a["scale"] = float(rng.choice([0.3, 0.9, 2.0]))
+            if "offset" in a and isinstance(a["offset"], float):
+                a["offset"] = float(rng.choice([0.0, 0.7, -0.2]))
+            if n == "all_ema":
+                a["alpha"] = {".*HAA": float(rng.choice([0.3, 1.0])), ".*HFE": float(rng.choice([0.75, 0.1])), ".*KFE": 1.0} if rng.random() < 0.7 else float(rng.choice([0.5, 1.0]))
+            if rng.random() < 0.3:
+                a["clip"] = None
+            env["actions"][n] = a
+        what.append("actions " + "+".join(keep_a))
     return fx, "; ".join(what)
 
 
@@ -136,6 +155,7 @@ def one_case(case_seed: int) -> str:
     W = sum(int(np.prod(env.observation_manager.group_obs_dim[g])) for g in groups)  # wide enough for every group's columns
     env._noise_u = torch.rand(N, W, generator=gen).cuda()
     obs0, _ = env.reset()
+    orc.reset_action_terms()  # ActionManager.reset of env.reset(): the EMA term's previous applied action <- the joint positions
     if env.plan.num_rays:
         orc.ray_hits_w = env._ray_hits.cpu()
     ref0 = orc.compute_observation_groups(env._noise_u.cpu())
@@ -150,6 +170,12 @@ def one_case(case_seed: int) -> str:
         env._noise_u.copy_(u)
         obs_dict, rew, term, tout, extras = env.step(a.cuda())
         orc.process_action(a)
+        pa, po = env._processed_action.cpu(), orc.processed_actions
+        badc = ((pa - po).abs() > FLOAT_TOL * po.abs().clamp(min=1.0)).any(0).nonzero().flatten().tolist()
+        if badc:
+            raise AssertionError(f"processed actions step {_}: columns {badc} differ (max {float((pa - po).abs().max()):.3e}); terms "
+                                 + json.dumps({n: {k: v for k, v in a.items() if k in ('class_type', 'scale', 'offset', 'clip', 'alpha', 'joint_names', 'use_zero_offset', 'use_default_offset', 'rescale_to_limits')}
+                                               for n, a in fx["env"]["actions"].items()}))
         cpu_feed.advance()
         if env.plan.num_rays:
             orc.ray_hits_w = env._ray_hits.cpu()
