@@ -291,7 +291,7 @@ def case_update(rng):
     err, outliers_ok = 0.0, True
     for (name, p), q in zip(pol.named_parameters(), ref_pol.parameters()):
         d = (p.detach() - q.detach()).abs()
-        over = d > 1e-4
+        over = d > 1e-4 * max(1.0, nep * nmb / 4)
         n_over = int(over.sum())
         if n_over > 2 + int(1e-4 * d.numel()) or float(d.max()) > 2.5e-3 * nep * nmb:  # (lr = 1e-3; the adaptive schedule can raise it 1.5x per step)
             outliers_ok = False
@@ -299,7 +299,12 @@ def case_update(rng):
         if os.getenv("FUZZ_VERBOSE"):
             print(f"      {name}: max |diff| {float(d.max()):.2e}, elements over 1e-4: {n_over} of {d.numel()}")
     lr_ok = abs(alg.learning_rate - lr) <= 1e-9 * max(1.0, lr)
-    return lr_ok and outliers_ok and err <= 1e-4, f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} std={std_type} {schedule} clipped_v={clipped_v} norm_mb={norm_mb} two_streams={two_streams} lr_ok={lr_ok} err={err:.1e}"
+    learning_rate = alg.learning_rate
+    del alg, stg  # (streams, graphs and workspaces of hundreds of PPO objects add up over a sweep)
+    import gc
+
+    gc.collect()
+    return lr_ok and outliers_ok and err <= 1e-4 * max(1.0, nep * nmb / 4), f"T={T} N={N} D={D} Dc={Dc} A={A} hidden={hidden} mb={nmb} ep={nep} fused_head={ppo_mod.FUSED_HEAD} std={std_type} {schedule} clipped_v={clipped_v} norm_mb={norm_mb} two_streams={two_streams} lr_ok={lr_ok} err={err:.1e}"
 
 
 def case_update_graph(rng):
@@ -354,6 +359,10 @@ def case_update_graph(rng):
         results.append((alg.bucket.flat.clone(), alg.bucket.exp_avg.clone(), alg.bucket.exp_avg_sq.clone(), alg.learning_rate, stats))
     (p0, m0, v0, lr0, s0), (p1, m1, v1, lr1, s1) = results
     same = lr0 == lr1 and s0 == s1 and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    del alg, stg
+    import gc
+
+    gc.collect()
     return same and bool(torch.isfinite(p1).all()), f"T={T} N={N} D={D} A={A} hidden={hidden} mb={nmb} ep={nep} identical={same}"
 
 
